@@ -1,0 +1,183 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/gs_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+`cpu_baseline` leg of bench.py -- never by the product package.  Mirrors the
+two-phase shape of the reference's Rasterizer::forward / ::backward
+(submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.cu:198-434)
+and of simple-knn's distCUDA2 (submodules/simple-knn/spatial.cu:15-26), and
+returns every intermediate so the HIP path can be compared stage by stage.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f = ctypes.POINTER(ctypes.c_float)
+_i = ctypes.POINTER(ctypes.c_int)
+_u8 = ctypes.POINTER(ctypes.c_uint8)
+_u32 = ctypes.POINTER(ctypes.c_uint32)
+_u64 = ctypes.POINTER(ctypes.c_uint64)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "gs_oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.orc_preprocess.restype = ctypes.c_long
+        _LIB.gs_expf.restype = ctypes.c_float
+        _LIB.gs_expf.argtypes = [ctypes.c_float]
+        _LIB.orc_getHigherMsb.restype = ctypes.c_uint32
+        _LIB.orc_getHigherMsb.argtypes = [ctypes.c_uint32]
+    return _LIB
+
+
+def _p(a, ty):
+    if a is None:
+        return ctypes.cast(None, ty)
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ty)
+
+
+def _f32(a):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    return a if a.size else None
+
+
+def gs_expf(x):
+    L = lib()
+    x = np.asarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    for k, v in enumerate(x.ravel()):
+        out.ravel()[k] = L.gs_expf(ctypes.c_float(float(v)))
+    return out
+
+
+def forward(means3D, opacities, *, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+            viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, sh_degree=0, scale_modifier=1.0):
+    """Full forward (K1..K7).  Returns a dict with out_color, radii and every intermediate."""
+    L = lib()
+    means3D = _f32(means3D).reshape(-1, 3) if np.asarray(means3D).size else np.zeros((0, 3), np.float32)
+    P = means3D.shape[0]
+    shs = _f32(shs); colors_precomp = _f32(colors_precomp); scales = _f32(scales)
+    rotations = _f32(rotations); cov3D_precomp = _f32(cov3D_precomp)
+    opacities = _f32(opacities)
+    M = shs.reshape(P, -1, 3).shape[1] if shs is not None else 0
+    vm = _f32(viewmatrix).reshape(16); pm = _f32(projmatrix).reshape(16)
+    cp = _f32(campos).reshape(3); bgc = _f32(bg).reshape(3)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    st = dict(P=P, W=W, H=H, M=M, D=sh_degree)
+    st["radii"] = np.zeros(P, np.int32)
+    st["means2D"] = np.zeros((P, 2), np.float32)
+    st["depths"] = np.zeros(P, np.float32)
+    st["cov3D"] = np.zeros((P, 6), np.float32)
+    st["rgb"] = np.zeros((P, 3), np.float32)
+    st["conic_opacity"] = np.zeros((P, 4), np.float32)
+    st["clamped"] = np.zeros((P, 3), np.uint8)
+    st["tiles_touched"] = np.zeros(P, np.uint32)
+    st["point_offsets"] = np.zeros(P, np.uint32)
+    st["out_color"] = np.zeros((3, H, W), np.float32)
+    st["final_T"] = np.zeros((H, W), np.float32)
+    st["n_contrib"] = np.zeros((H, W), np.uint32)
+    st["ranges"] = np.zeros((gx * gy, 2), np.uint32)
+    R = 0
+    if P > 0:
+        R = L.orc_preprocess(
+            ctypes.c_int(P), ctypes.c_int(sh_degree), ctypes.c_int(M), _p(means3D, _f), _p(scales, _f),
+            ctypes.c_float(scale_modifier), _p(rotations, _f), _p(opacities, _f), _p(shs, _f), _p(cov3D_precomp, _f),
+            _p(colors_precomp, _f), _p(vm, _f), _p(pm, _f), _p(cp, _f), ctypes.c_int(W), ctypes.c_int(H),
+            ctypes.c_float(tanfovx), ctypes.c_float(tanfovy), _p(st["radii"], _i), _p(st["means2D"], _f),
+            _p(st["depths"], _f), _p(st["cov3D"], _f), _p(st["rgb"], _f), _p(st["conic_opacity"], _f),
+            _p(st["clamped"], _u8), _p(st["tiles_touched"], _u32), _p(st["point_offsets"], _u32))
+    st["num_rendered"] = int(R)
+    n = max(R, 1)
+    st["keys_unsorted"] = np.zeros(n, np.uint64)[:R]
+    st["values_unsorted"] = np.zeros(n, np.uint32)[:R]
+    st["keys_sorted"] = np.zeros(n, np.uint64)[:R]
+    st["point_list"] = np.zeros(n, np.uint32)[:R]
+    st["stats"] = np.zeros(3, np.int64)
+    if P > 0:
+        L.orc_binning(ctypes.c_int(P), ctypes.c_long(R), ctypes.c_int(W), ctypes.c_int(H), _p(st["radii"], _i),
+                      _p(st["means2D"], _f), _p(st["depths"], _f), _p(st["point_offsets"], _u32),
+                      _p(st["keys_unsorted"], _u64), _p(st["values_unsorted"], _u32), _p(st["keys_sorted"], _u64),
+                      _p(st["point_list"], _u32), _p(st["ranges"], _u32))
+        feats = colors_precomp if colors_precomp is not None else st["rgb"]
+        L.orc_render_forward(ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32), _p(st["point_list"], _u32),
+                             _p(st["means2D"], _f), _p(feats, _f), _p(st["conic_opacity"], _f), _p(bgc, _f),
+                             _p(st["final_T"], _f), _p(st["n_contrib"], _u32), _p(st["out_color"], _f),
+                             st["stats"].ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
+    # the reference fills out_color with 0 when P == 0 (rasterize_points.cu:68, :82)
+    st["_inputs"] = dict(means3D=means3D, opacities=opacities, shs=shs, colors_precomp=colors_precomp, scales=scales,
+                         rotations=rotations, cov3D_precomp=cov3D_precomp, vm=vm, pm=pm, cp=cp, bg=bgc,
+                         tanfovx=tanfovx, tanfovy=tanfovy, scale_modifier=scale_modifier)
+    return st
+
+
+def backward(st, dL_dpix):
+    """Full backward (K8..K10) for a state returned by forward()."""
+    L = lib()
+    P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
+    inp = st["_inputs"]
+    dL_dpix = _f32(dL_dpix).reshape(3, H, W)
+    g = dict(
+        dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
+        dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolors=np.zeros((P, 3), np.float32),
+        dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
+        dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
+        dL_drotations=np.zeros((P, 4), np.float32))
+    if P == 0:
+        return g
+    colors = inp["colors_precomp"] if inp["colors_precomp"] is not None else st["rgb"]
+    cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else st["cov3D"]
+    L.orc_render_backward(ctypes.c_int(P), ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32),
+                          _p(st["point_list"], _u32), _p(inp["bg"], _f), _p(st["means2D"], _f),
+                          _p(st["conic_opacity"], _f), _p(colors, _f), _p(st["final_T"], _f), _p(st["n_contrib"], _u32),
+                          _p(dL_dpix, _f), _p(g["dL_dmeans2D"], _f), _p(g["dL_dconic"], _f), _p(g["dL_dopacity"], _f),
+                          _p(g["dL_dcolors"], _f))
+    L.orc_preprocess_backward(
+        ctypes.c_int(P), ctypes.c_int(D), ctypes.c_int(M), _p(inp["means3D"], _f), _p(st["radii"], _i),
+        _p(inp["shs"], _f), _p(st["clamped"], _u8), _p(inp["scales"], _f), _p(inp["rotations"], _f),
+        ctypes.c_float(inp["scale_modifier"]), _p(cov3D, _f), _p(inp["vm"], _f), _p(inp["pm"], _f), ctypes.c_int(W),
+        ctypes.c_int(H), ctypes.c_float(inp["tanfovx"]), ctypes.c_float(inp["tanfovy"]), _p(inp["cp"], _f),
+        _p(g["dL_dmeans2D"], _f), _p(g["dL_dconic"], _f), _p(g["dL_dmeans3D"], _f), _p(g["dL_dcolors"], _f),
+        _p(g["dL_dcov3D"], _f), _p(g["dL_dsh"], _f), _p(g["dL_dscales"], _f), _p(g["dL_drotations"], _f))
+    return g
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    L = lib()
+    means3D = _f32(means3D)
+    P = 0 if means3D is None else means3D.reshape(-1, 3).shape[0]
+    out = np.zeros(P, np.uint8)
+    if P:
+        L.orc_mark_visible(ctypes.c_int(P), _p(means3D, _f), _p(_f32(viewmatrix).reshape(16), _f),
+                           _p(_f32(projmatrix).reshape(16), _f), _p(out, _u8))
+    return out.astype(bool)
+
+
+def knn_mean_dist2(points, bruteforce=False):
+    """distCUDA2: mean squared distance to the 3 nearest other points."""
+    L = lib()
+    pts = _f32(points)
+    P = 0 if pts is None else pts.reshape(-1, 3).shape[0]
+    out = np.zeros(P, np.float32)
+    if P:
+        fn = L.orc_knn_bruteforce if bruteforce else L.orc_knn_mean_dist2
+        fn(ctypes.c_int(P), _p(pts, _f), _p(out, _f))
+    return out
