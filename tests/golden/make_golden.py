@@ -1,0 +1,113 @@
+"""Generates the committed fixtures under tests/golden/ (run in the BUILD container only).
+
+Two kinds of vectors:
+  ref_*.npz    -- outputs of the REFERENCE's own importable Python helpers
+                  (/root/reference/utils/sh_utils.py, utils/graphics_utils.py), the only parts of the hot
+                  path's arithmetic that exist outside CUDA.  They pin the oracle's SH->RGB and the camera
+                  matrix conventions.  The reference is imported, never copied.
+  oracle_*.npz -- a snapshot of the oracle's own outputs on a seeded scene (drift guard; the reference ships
+                  no golden vectors for the CUDA kernels: SURVEY.md §4, §8c).
+Usage: python tests/golden/make_golden.py
+"""
+import hashlib
+import importlib.util
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def ref_sh():
+    sh_utils = _load("ref_sh_utils", "utils/sh_utils.py")
+    g = torch.Generator().manual_seed(123)
+    P = 96
+    xyz = 4 * torch.rand(P, 3, generator=g) - 2
+    campos = torch.tensor([1.5, -2.0, 0.7])
+    shs = torch.cat((0.5 * torch.randn(P, 1, 3, generator=g), 0.3 * torch.randn(P, 15, 3, generator=g)), 1)
+    out = {"xyz": xyz.numpy(), "campos": campos.numpy(), "shs": shs.numpy()}
+    # gaussian_renderer/__init__.py:73-78 (the --convert_SHs_python path)
+    shs_view = shs.transpose(1, 2).view(-1, 3, 16)
+    dir_pp = xyz - campos.repeat(P, 1)
+    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    for deg in range(4):
+        sh2rgb = sh_utils.eval_sh(deg, shs_view[:, :, :(deg + 1) ** 2], dir_pp_normalized)
+        out[f"rgb_deg{deg}"] = torch.clamp_min(sh2rgb + 0.5, 0.0).numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_sh.npz"), **out)
+
+
+def ref_cameras():
+    gu = _load("ref_graphics_utils", "utils/graphics_utils.py")
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    out = {}
+    k = 0
+    for (W, H, focal, pos) in [(256, 256, 160.0, (6.0, 0.0, 2.0)), (1920, 1080, 1200.0, (0.0, 6.0, 2.0)),
+                                (640, 480, 500.0, (-3.0, 4.0, 1.0)), (1920, 1080, 1200.0, (4.2426, -4.2426, 2.0))]:
+        R, T = syn.look_at_RT(pos)
+        FoVx, FoVy = gu.focal2fov(focal, W), gu.focal2fov(focal, H)
+        # scene/cameras.py:109-112 on CPU
+        wvt = torch.tensor(gu.getWorld2View2(R, T, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+        proj = gu.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=FoVx, fovY=FoVy).transpose(0, 1)
+        full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+        center = wvt.inverse()[3, :3]
+        out[f"in{k}"] = np.array([W, H, focal, *pos], dtype=np.float64)
+        out[f"wvt{k}"] = wvt.numpy()
+        out[f"full{k}"] = full.numpy()
+        out[f"center{k}"] = center.numpy()
+        out[f"fov{k}"] = np.array([FoVx, FoVy])
+        k += 1
+    out["n"] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, "ref_cameras.npz"), **out)
+
+
+def _h(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def oracle_snapshot():
+    from helpers import oracle_forward, scene
+    from oracle import oracle
+
+    os.environ["OMP_NUM_THREADS"] = "1"
+    P, W, H, focal = 4000, 160, 128, 100.0
+    g, cam = scene(P, W, H, focal, seed=42, scale_lo=0.01, scale_hi=0.12)
+    st = oracle_forward(g, cam, bg=(0.1, 0.2, 0.3), sh_degree=3)
+    dL = np.random.default_rng(9).standard_normal((3, H, W)).astype(np.float32)
+    gr = oracle.backward(st, dL)
+    sub = np.random.default_rng(10).choice(P, 400, replace=False)
+    out = dict(cfg=np.array([P, W, H, focal, 42, 0.01, 0.12]), bg=np.array([0.1, 0.2, 0.3], np.float32),
+               num_rendered=np.array(st["num_rendered"]), radii=st["radii"], tiles_touched=st["tiles_touched"],
+               depth_bits=st["depths"].view(np.uint32), h_keys_sorted=_h(st["keys_sorted"]),
+               h_point_list=_h(st["point_list"]), ranges=st["ranges"], n_contrib=st["n_contrib"].astype(np.uint16),
+               out_color=st["out_color"], final_T=st["final_T"], sub=sub)
+    for k, v in gr.items():
+        out["g_" + k] = v[sub]
+        out["gsum_" + k] = np.array([np.abs(v.astype(np.float64)).sum()])
+    np.savez_compressed(os.path.join(HERE, "oracle_snapshot.npz"), **out)
+
+    pts = (np.random.default_rng(5).uniform(-3, 3, (5000, 3))).astype(np.float32)
+    pts[100] = pts[7]  # exact duplicate
+    np.savez_compressed(os.path.join(HERE, "oracle_knn.npz"), pts=pts, dist2=oracle.knn_mean_dist2(pts))
+
+
+if __name__ == "__main__":
+    ref_sh()
+    ref_cameras()
+    oracle_snapshot()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
