@@ -1,0 +1,92 @@
+"""ctypes binding of csrc/libgsrast_mi355x.so (C ABI: include/gsrast_mi355x.h).
+
+The HIP library is the product path.  There is deliberately NO fallback: if the
+shared object is missing, cannot be loaded, or a tensor is not on a HIP device,
+the operators raise.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
+ABI_VERSION = 1
+
+_lib = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_float = ctypes.c_float
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gsrast_mi355x.h one to one
+PROTOTYPES = {
+    "gsr_abi_version": (c_int, []),
+    "gsr_last_error": (ctypes.c_char_p, []),
+    "gsr_geometry_bytes": (c_size, [c_int]),
+    "gsr_image_bytes": (c_size, [c_int, c_int]),
+    "gsr_binning_bytes": (c_size, [c_i64]),
+    "gsr_backward_scratch_bytes": (c_size, [c_i64]),
+    "gsr_forward_geometry": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
+                                     c_void_p, c_size, ctypes.POINTER(c_i64), c_void_p]),
+    "gsr_forward_render": (c_int, [c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_size, c_void_p, c_size, c_void_p, c_size,
+                                   c_void_p, c_void_p]),
+    "gsr_backward": (c_int, [c_int, c_int, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_size,
+                             c_void_p, c_size, c_void_p, c_size, c_void_p, c_size, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_knn_scratch_bytes": (c_size, [c_int]),
+    "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),
+    "gsr_profile_enable": (None, [c_int]),
+    "gsr_profile_collect": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64), c_int]),
+    "gsr_sort_scratch_bytes": (c_size, [c_i64]),
+    "gsr_sort_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_size, c_void_p]),
+}
+
+
+class GsrError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (the reference throws std::runtime_error / AT_ERROR)."""
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise GsrError(f"HIP extension not built: {SO_PATH} is missing (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C based_on_point_cloud_partitions_amd/csrc`). There is no CPU fallback.")
+        lib = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError here = the .so does not export what the header declares
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gsr_abi_version() != ABI_VERSION:
+            raise GsrError(f"ABI mismatch: library {lib.gsr_abi_version()} != binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+STAGES = ["preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges", "render_forward", "render_backward",
+          "gaussian_backward"]
+
+
+def profile_enable(on):
+    load().gsr_profile_enable(1 if on else 0)
+
+
+def profile_collect():
+    """-> {stage: (total_ms, launches)} since the last collect."""
+    n = len(STAGES)
+    ms = (ctypes.c_double * n)()
+    cnt = (c_i64 * n)()
+    check(load().gsr_profile_collect(ms, cnt, n), "gsr_profile_collect")
+    return {STAGES[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+
+def check(status, what):
+    if status < 0:
+        msg = load().gsr_last_error()
+        raise GsrError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+    return status

@@ -1,0 +1,328 @@
+// extern "C" entry points of libgsrast_mi355x.so (declared in include/gsrast_mi355x.h).
+// Host-side orchestration only: buffer layouts, argument checks, stage launches on the caller's stream.
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/gsrast_mi355x.h"
+#include "common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, a);
+    return code;
+}
+
+int check_hip(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return -100;
+    }
+    return 0;
+}
+
+// ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline figures) ----
+struct ProfRec { int stage; hipEvent_t a, b; };
+bool g_prof = false;
+std::vector<ProfRec> g_recs;
+std::mutex g_prof_mu;
+
+struct StageTimer {
+    int stage; hipStream_t s; hipEvent_t a, b; bool on;
+    StageTimer(int stage_, hipStream_t s_) : stage(stage_), s(s_), on(g_prof)
+    {
+        if (on) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, s);
+        }
+    }
+    ~StageTimer()
+    {
+        if (on) {
+            hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_recs.push_back({stage, a, b});
+        }
+    }
+};
+
+__global__ void __launch_bounds__(256) export_geom_kernel(int P, const float* __restrict__ splat, float* means2D, float* depths,
+                                                          float* conic_opacity, float* rgb)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float* r = splat + (size_t)i * GSR_SPLAT_F;
+    if (means2D) { means2D[2 * i] = r[SP_MX]; means2D[2 * i + 1] = r[SP_MY]; }
+    if (depths) depths[i] = r[SP_DEPTH];
+    if (conic_opacity) {
+        conic_opacity[4 * i] = r[SP_CX]; conic_opacity[4 * i + 1] = r[SP_CY];
+        conic_opacity[4 * i + 2] = r[SP_CZ]; conic_opacity[4 * i + 3] = r[SP_OPA];
+    }
+    if (rgb) { rgb[3 * i] = r[SP_R]; rgb[3 * i + 1] = r[SP_G]; rgb[3 * i + 2] = r[SP_B]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+const char* gsr_last_error(void) { return g_err; }
+
+size_t gsr_geometry_bytes(int P) { return gsr_geom_layout(P).bytes; }
+size_t gsr_image_bytes(int W, int H) { return gsr_image_layout(W, H).bytes; }
+size_t gsr_binning_bytes(int64_t R) { return gsr_bin_layout((long)R).bytes; }
+size_t gsr_backward_scratch_bytes(int64_t R) { return gsr_align((size_t)(R > 0 ? R : 1) * GSR_GROW_F * 4); }
+
+int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                         const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                         const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                         int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* geom_buffer,
+                         size_t geom_bytes, int64_t* num_rendered_host, void* stream)
+{
+    (void)prefiltered;  // only selects a device-side trap in the reference (auxiliary.h:156-160)
+    hipStream_t s = (hipStream_t)stream;
+    if (!num_rendered_host) return fail(-1, "num_rendered_host is NULL");
+    *num_rendered_host = 0;
+    if (P < 0 || W <= 0 || H <= 0) return fail(-1, "invalid sizes");
+    if (P == 0) return 0;
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer)
+        return fail(-1, "NULL required pointer");
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(-2, "provide exactly one of shs / colors_precomp");
+    if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
+        return fail(-2, "provide scales+rotations or cov3D_precomp");
+    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(-2, "SH degree / coefficient count mismatch");
+    const GeomLayout L = gsr_geom_layout(P);
+    if (geom_bytes < L.bytes) return fail(-3, "geometry buffer too small");
+    char* g = (char*)geom_buffer;
+    PreprocessArgs a;
+    a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
+    a.means3D = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.shs = shs;
+    a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
+    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.radii = radii;
+    a.splat = (float*)(g + L.splat); a.cov3D = (float*)(g + L.cov3D); a.clamped = (uint8_t*)(g + L.clamped);
+    a.tiles_touched = (uint32_t*)(g + L.tiles_touched); a.block_sums = (uint32_t*)(g + L.block_sums);
+    { StageTimer t(GSR_STAGE_PREPROCESS, s); gsr_launch_preprocess(a, s); }
+    const int nb = (P + 255) / 256;
+    { StageTimer t(GSR_STAGE_SCAN, s); gsr_launch_scan_blocks(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), s); }
+    uint32_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, g + L.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(-100, "forward_geometry: %s", hipGetErrorString(e));
+    *num_rendered_host = (int64_t)total;
+    return check_hip("forward_geometry");
+}
+
+int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, void* geom_buffer, size_t geom_bytes,
+                       void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes,
+                       float* out_color, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return 0;
+    if (!background || !geom_buffer || !image_buffer || !out_color) return fail(-1, "NULL required pointer");
+    if (R < 0 || R > 0xFFFFFFFFll) return fail(-1, "num_rendered out of range");
+    const GeomLayout G = gsr_geom_layout(P);
+    const ImageLayout I = gsr_image_layout(W, H);
+    const BinLayout B = gsr_bin_layout((long)R);
+    if (geom_bytes < G.bytes) return fail(-3, "geometry buffer too small");
+    if (image_bytes < I.bytes) return fail(-3, "image buffer too small");
+    if (R > 0 && (!binning_buffer || binning_bytes < B.bytes)) return fail(-3, "binning buffer too small");
+    char* g = (char*)geom_buffer;
+    char* b = (char*)binning_buffer;
+    char* im = (char*)image_buffer;
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    uint32_t* ranges = (uint32_t*)(im + I.ranges);
+    const uint32_t* point_list = nullptr;
+    if (R > 0) {
+        uint64_t* ka = (uint64_t*)(b + B.keys_a);
+        uint64_t* kb = (uint64_t*)(b + B.keys_b);
+        uint32_t* va = (uint32_t*)(b + B.vals_a);
+        uint32_t* vb = (uint32_t*)(b + B.vals_b);
+        {
+            StageTimer t(GSR_STAGE_EMIT, s);
+            gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
+                            (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets), ka, va, s);
+        }
+        const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));  // rasterizer_impl.cu:300-308
+        int in_b;
+        {
+            StageTimer t(GSR_STAGE_SORT, s);
+            in_b = gsr_launch_radix_sort(ka, kb, va, vb, (uint32_t)R, end_bit, (uint32_t*)(b + B.hist_global),
+                                         (uint32_t*)(b + B.hist_blocks), B.sort_blocks, s);
+        }
+        { StageTimer t(GSR_STAGE_RANGES, s); gsr_launch_tile_ranges((uint32_t)R, in_b ? kb : ka, ranges, (uint32_t)(gx * gy), s); }
+        point_list = in_b ? vb : va;
+    } else {
+        // point_offsets must still be valid for the backward pass; no instances -> all ranges empty
+        hipMemsetAsync(g + G.point_offsets, 0, (size_t)P * 4, s);
+        gsr_launch_tile_ranges(0, nullptr, ranges, (uint32_t)(gx * gy), s);
+    }
+    {
+        StageTimer t(GSR_STAGE_RENDER_FWD, s);
+        gsr_launch_render_forward(W, H, ranges, point_list, (const float*)(g + G.splat), background, (float*)(im + I.final_T),
+                                  (uint32_t*)(im + I.n_contrib), out_color, s);
+    }
+    return check_hip("forward_render");
+}
+
+int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
+                 size_t geom_bytes, const void* binning_buffer, size_t binning_bytes, const void* image_buffer,
+                 size_t image_bytes, void* scratch, size_t scratch_bytes, const float* dL_dpix, float* dL_dmeans2D,
+                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscales, float* dL_drotations, void* stream)
+{
+    (void)colors_precomp;
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return 0;
+    if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer || !dL_dpix ||
+        !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations)
+        return fail(-1, "NULL required pointer");
+    if (M > 0 && !dL_dsh) return fail(-1, "dL_dsh is NULL");
+    const GeomLayout G = gsr_geom_layout(P);
+    const ImageLayout I = gsr_image_layout(W, H);
+    const BinLayout B = gsr_bin_layout((long)R);
+    if (geom_bytes < G.bytes || image_bytes < I.bytes) return fail(-3, "state buffer too small");
+    if (R > 0 && (!binning_buffer || binning_bytes < B.bytes)) return fail(-3, "binning buffer too small");
+    if (R > 0 && (!scratch || scratch_bytes < gsr_backward_scratch_bytes(R))) return fail(-3, "backward scratch too small");
+    const char* g = (const char*)geom_buffer;
+    const char* b = (const char*)binning_buffer;
+    const char* im = (const char*)image_buffer;
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    if (R > 0) {
+        const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));
+        const uint32_t* point_list = (const uint32_t*)(b + (gsr_sort_result_in_b(end_bit) ? B.vals_b : B.vals_a));
+        StageTimer t(GSR_STAGE_RENDER_BWD, s);
+        gsr_launch_render_backward(W, H, (const uint32_t*)(im + I.ranges), point_list, (const float*)(g + G.splat), background,
+                                   (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
+                                   (float*)scratch, s);
+    }
+    GaussBackwardArgs a;
+    a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
+    a.means3D = means3D; a.shs = shs; a.scales = scales; a.rotations = rotations;
+    a.cov3D_in = cov3D_precomp ? cov3D_precomp : (const float*)(g + G.cov3D);
+    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
+    a.radii = radii; a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);
+    a.tiles_touched = (const uint32_t*)(g + G.tiles_touched);
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.has_shs = shs != nullptr; a.has_scales = scales != nullptr;
+    a.grad_rows = (const float*)scratch;
+    a.dL_dmeans2D = dL_dmeans2D; a.dL_dcolors = dL_dcolors; a.dL_dopacity = dL_dopacity; a.dL_dmeans3D = dL_dmeans3D;
+    a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales; a.dL_drots = dL_drotations;
+    { StageTimer t(GSR_STAGE_GAUSS_BWD, s); gsr_launch_gaussian_backward(a, s); }
+    return check_hip("backward");
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream)
+{
+    (void)projmatrix;
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail(-1, "NULL required pointer");
+    gsr_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    return check_hip("mark_visible");
+}
+
+size_t gsr_knn_scratch_bytes(int P) { return gsr_knn_scratch_layout_bytes(P); }
+
+int gsr_knn_mean_dist2(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (P == 0) return 0;
+    if (!points || !out || !scratch) return fail(-1, "NULL required pointer");
+    if (gsr_knn_run(P, points, out, scratch, scratch_bytes, (hipStream_t)stream) != 0) return fail(-3, "knn scratch too small");
+    return check_hip("knn_mean_dist2");
+}
+
+int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, const void* binning_buffer,
+                     const void* image_buffer, float* means2D, float* depths, float* conic_opacity, float* rgb, float* cov3D,
+                     uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_offsets, uint64_t* keys_sorted,
+                     uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return 0;
+    const GeomLayout G = gsr_geom_layout(P);
+    const ImageLayout I = gsr_image_layout(W, H);
+    const BinLayout B = gsr_bin_layout((long)R);
+    const char* g = (const char*)geom_buffer;
+    const char* b = (const char*)binning_buffer;
+    const char* im = (const char*)image_buffer;
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    const size_t N = (size_t)W * H;
+    if (g) {
+        hipLaunchKernelGGL(export_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, (const float*)(g + G.splat), means2D, depths,
+                           conic_opacity, rgb);
+        if (cov3D) hipMemcpyAsync(cov3D, g + G.cov3D, (size_t)P * 24, hipMemcpyDeviceToDevice, s);
+        if (clamped) hipMemcpyAsync(clamped, g + G.clamped, (size_t)P * 3, hipMemcpyDeviceToDevice, s);
+        if (tiles_touched) hipMemcpyAsync(tiles_touched, g + G.tiles_touched, (size_t)P * 4, hipMemcpyDeviceToDevice, s);
+        if (point_offsets) hipMemcpyAsync(point_offsets, g + G.point_offsets, (size_t)P * 4, hipMemcpyDeviceToDevice, s);
+    }
+    if (b && R > 0) {
+        const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));
+        const int in_b = gsr_sort_result_in_b(end_bit);
+        if (keys_sorted) hipMemcpyAsync(keys_sorted, b + (in_b ? B.keys_b : B.keys_a), (size_t)R * 8, hipMemcpyDeviceToDevice, s);
+        if (point_list) hipMemcpyAsync(point_list, b + (in_b ? B.vals_b : B.vals_a), (size_t)R * 4, hipMemcpyDeviceToDevice, s);
+    }
+    if (im) {
+        if (ranges) hipMemcpyAsync(ranges, im + I.ranges, (size_t)gx * gy * 8, hipMemcpyDeviceToDevice, s);
+        if (final_T) hipMemcpyAsync(final_T, im + I.final_T, N * 4, hipMemcpyDeviceToDevice, s);
+        if (n_contrib) hipMemcpyAsync(n_contrib, im + I.n_contrib, N * 4, hipMemcpyDeviceToDevice, s);
+    }
+    return check_hip("debug_export");
+}
+
+void gsr_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof = on != 0;
+}
+
+int gsr_profile_collect(double* ms_per_stage, int64_t* launches_per_stage, int nstages)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < nstages; i++) { ms_per_stage[i] = 0.0; launches_per_stage[i] = 0; }
+    int rc = 0;
+    for (const ProfRec& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = -100;
+        else if (r.stage < nstages) { ms_per_stage[r.stage] += ms; launches_per_stage[r.stage] += 1; }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    return rc;
+}
+
+size_t gsr_sort_scratch_bytes(int64_t n)
+{
+    const BinLayout B = gsr_bin_layout((long)n);
+    return gsr_align(8 * 256 * 4) + gsr_align((size_t)B.sort_blocks * 256 * 4);
+}
+
+int gsr_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t n, int end_bit,
+                   void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (n < 0 || n > 0xFFFFFFFFll || end_bit < 1 || end_bit > 64) return fail(-1, "invalid sort arguments");
+    if (n == 0) return ((end_bit + 7) / 8) & 1;
+    if (!keys_a || !keys_b || !vals_a || !vals_b || !scratch) return fail(-1, "NULL required pointer");
+    if (scratch_bytes < gsr_sort_scratch_bytes(n)) return fail(-3, "sort scratch too small");
+    const BinLayout B = gsr_bin_layout((long)n);
+    uint32_t* hg = (uint32_t*)scratch;
+    uint32_t* hb = (uint32_t*)((char*)scratch + gsr_align(8 * 256 * 4));
+    const int r = gsr_launch_radix_sort(keys_a, keys_b, vals_a, vals_b, (uint32_t)n, end_bit, hg, hb, B.sort_blocks, (hipStream_t)stream);
+    const int c = check_hip("sort_pairs");
+    return c ? c : r;
+}
+
+}  // extern "C"

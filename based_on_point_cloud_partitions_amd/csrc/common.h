@@ -1,0 +1,169 @@
+// Shared declarations of the MI355X (gfx950) Gaussian-rasterizer library.
+// Internal header: the public C ABI is include/gsrast_mi355x.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define GSR_TILE_X 16
+#define GSR_TILE_Y 16
+#define GSR_TILE_PIX 256
+#define GSR_SPLAT_F 12   // floats per packed per-Gaussian record (48 B)
+#define GSR_GROW_F 12    // floats per per-instance gradient row (48 B)
+
+// Packed per-Gaussian record written by the preprocess kernel and gathered by the blend kernels.
+// One 48-byte row (3 x 16 B loads) instead of the reference's four separate arrays
+// (means2D / conic_opacity / rgb / depths, rasterizer_impl.h:29-45).
+enum SplatField {
+    SP_MX = 0, SP_MY = 1, SP_CX = 2, SP_CY = 3, SP_CZ = 4, SP_OPA = 5,
+    SP_R = 6, SP_G = 7, SP_B = 8, SP_DEPTH = 9, SP_RADIUS = 10 /* int bits */, SP_OFFS = 11 /* uint bits: exclusive instance offset */
+};
+
+// Per-instance gradient row written by the backward blend kernel, summed per Gaussian afterwards.
+enum GradRowField { GR_MX = 0, GR_MY = 1, GR_CX = 2, GR_CY = 3, GR_CW = 4, GR_OPA = 5, GR_R = 6, GR_G = 7, GR_B = 8 };
+
+struct GeomLayout {
+    size_t splat, cov3D, clamped, tiles_touched, point_offsets, block_sums, block_offsets, total, radii, bytes;
+};
+struct ImageLayout {
+    size_t final_T, n_contrib, ranges, bytes;
+};
+struct BinLayout {
+    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, bytes;
+    uint32_t sort_blocks;
+};
+
+static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline GeomLayout gsr_geom_layout(int P)
+{
+    GeomLayout L;
+    size_t o = 0, p = (size_t)(P > 0 ? P : 1);
+    size_t nb = (p + 255) / 256;
+    L.splat = o; o = gsr_align(o + p * GSR_SPLAT_F * 4);
+    L.cov3D = o; o = gsr_align(o + p * 6 * 4);
+    L.clamped = o; o = gsr_align(o + p * 3);
+    L.tiles_touched = o; o = gsr_align(o + p * 4);
+    L.point_offsets = o; o = gsr_align(o + p * 4);
+    L.block_sums = o; o = gsr_align(o + nb * 4);
+    L.block_offsets = o; o = gsr_align(o + nb * 4);
+    L.total = o; o = gsr_align(o + 16);
+    L.radii = o; o = gsr_align(o + p * 4);
+    L.bytes = o;
+    return L;
+}
+static inline ImageLayout gsr_image_layout(int W, int H)
+{
+    ImageLayout L;
+    size_t o = 0, n = (size_t)W * H;
+    size_t t = (size_t)((W + GSR_TILE_X - 1) / GSR_TILE_X) * ((H + GSR_TILE_Y - 1) / GSR_TILE_Y);
+    if (n == 0) n = 1;
+    if (t == 0) t = 1;
+    L.final_T = o; o = gsr_align(o + n * 4);
+    L.n_contrib = o; o = gsr_align(o + n * 4);
+    L.ranges = o; o = gsr_align(o + t * 8);
+    L.bytes = o;
+    return L;
+}
+
+#define GSR_SORT_THREADS 256
+#define GSR_SORT_ITEMS 16
+#define GSR_SORT_TILE (GSR_SORT_THREADS * GSR_SORT_ITEMS)
+
+static inline BinLayout gsr_bin_layout(long R)
+{
+    BinLayout L;
+    size_t o = 0, r = (size_t)(R > 0 ? R : 1);
+    L.sort_blocks = (uint32_t)((r + GSR_SORT_TILE - 1) / GSR_SORT_TILE);
+    L.keys_a = o; o = gsr_align(o + r * 8);
+    L.keys_b = o; o = gsr_align(o + r * 8);
+    L.vals_a = o; o = gsr_align(o + r * 4);
+    L.vals_b = o; o = gsr_align(o + r * 4);
+    L.hist_global = o; o = gsr_align(o + 8 * 256 * 4);
+    L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
+    L.bytes = o;
+    return L;
+}
+
+// rasterizer_impl.cu:35-50 (number of key bits that hold the tile id)
+static inline uint32_t gsr_higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+// ---- launchers (one per stage), all asynchronous on `stream` ----
+struct PreprocessArgs {
+    int P, D, M, W, H;
+    const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
+    const float *viewmatrix, *projmatrix, *campos;
+    float scale_modifier, tan_fovx, tan_fovy;
+    int* radii;
+    float* splat; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched; uint32_t* block_sums;
+};
+void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s);
+void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, hipStream_t s);
+void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
+                     uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s);
+// returns 0 if the sorted pairs end in (ka,va), 1 if in (kb,vb)
+int gsr_launch_radix_sort(uint64_t* ka, uint64_t* kb, uint32_t* va, uint32_t* vb, uint32_t n, int end_bit,
+                          uint32_t* hist_global, uint32_t* hist_blocks, uint32_t nblocks, hipStream_t s);
+static inline int gsr_sort_result_in_b(int end_bit) { return (((end_bit + 7) / 8) & 1); }
+void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
+void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
+                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, hipStream_t s);
+void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
+                                const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
+                                float* grad_rows, hipStream_t s);
+struct GaussBackwardArgs {
+    int P, D, M, W, H;
+    const float *means3D, *shs, *scales, *rotations, *cov3D_in /* precomp or computed */, *viewmatrix, *projmatrix, *campos;
+    const int* radii; const uint8_t* clamped; const float* splat; const uint32_t* tiles_touched;
+    float scale_modifier, tan_fovx, tan_fovy;
+    int has_shs, has_scales;
+    const float* grad_rows;
+    float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
+};
+void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s);
+void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+
+size_t gsr_knn_scratch_layout_bytes(int P);
+int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
+
+// ---- device helpers ----
+#ifdef __HIPCC__
+// The blend's exp(): same fully specified algorithm as the oracle's gs_expf (independently written).
+__device__ __forceinline__ float gsr_expf(float x)
+{
+    if (x < -80.0f) return 0.0f;
+    x = x > 80.0f ? 80.0f : x;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    return __int_as_float(__float_as_int(y) + ((int)n << 23));
+}
+
+// auxiliary.h:46-56 -- tile rectangle of a splat (saturating float->int as the hardware converts)
+__device__ __forceinline__ void gsr_get_rect(float px, float py, int max_radius, int gx, int gy,
+                                             uint32_t& minx, uint32_t& miny, uint32_t& maxx, uint32_t& maxy)
+{
+    const float r = (float)max_radius;
+    minx = (uint32_t)min(gx, max(0, (int)((px - r) / (float)GSR_TILE_X)));
+    miny = (uint32_t)min(gy, max(0, (int)((py - r) / (float)GSR_TILE_Y)));
+    maxx = (uint32_t)min(gx, max(0, (int)((px + r + (float)(GSR_TILE_X - 1)) / (float)GSR_TILE_X)));
+    maxy = (uint32_t)min(gy, max(0, (int)((py + r + (float)(GSR_TILE_Y - 1)) / (float)GSR_TILE_Y)));
+}
+#endif

@@ -1,0 +1,259 @@
+// Per-Gaussian backward for MI355X: sums the per-instance gradient rows written by the blend backward, then
+// back-propagates through the conic/2D covariance (computeCov2DCUDA, cuda_rasterizer/backward.cu:144-274),
+// the projection of the mean, the SH colour and the scale/rotation -> 3D covariance
+// (preprocessCUDA + computeColorFromSH + computeCov3D, backward.cu:20-139,278-396) in ONE pass.
+// Every output element is written exactly once (zeros for culled Gaussians), so the 300 B/Gaussian of
+// torch::zeros the reference needs per call (rasterize_points.cu:151-159) disappear.
+#include "common.h"
+
+namespace {
+
+__constant__ float bSH_C0 = 0.28209479177387814f;
+__constant__ float bSH_C1 = 0.4886025119029199f;
+__constant__ float bSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                -0.5900435899266435f};
+
+__global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardArgs a, float h_x, float h_y)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    const int M = a.M;
+    float* o_m2 = a.dL_dmeans2D + 3 * (size_t)idx;
+    float* o_col = a.dL_dcolors + 3 * (size_t)idx;
+    float* o_m3 = a.dL_dmeans3D + 3 * (size_t)idx;
+    float* o_cov = a.dL_dcov3D + 6 * (size_t)idx;
+    float* o_sh = a.dL_dsh + (size_t)idx * M * 3;
+    float* o_sc = a.dL_dscales + 3 * (size_t)idx;
+    float* o_rot = a.dL_drots + 4 * (size_t)idx;
+
+    if (!(a.radii[idx] > 0)) {
+        o_m2[0] = 0.f; o_m2[1] = 0.f; o_m2[2] = 0.f;
+        o_col[0] = 0.f; o_col[1] = 0.f; o_col[2] = 0.f;
+        a.dL_dopacity[idx] = 0.f;
+        o_m3[0] = 0.f; o_m3[1] = 0.f; o_m3[2] = 0.f;
+        for (int i = 0; i < 6; i++) o_cov[i] = 0.f;
+        for (int i = 0; i < 3 * M; i++) o_sh[i] = 0.f;
+        o_sc[0] = 0.f; o_sc[1] = 0.f; o_sc[2] = 0.f;
+        reinterpret_cast<float4*>(o_rot)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+
+    // ---- sum this Gaussian's gradient rows (fixed order -> reproducible) ----
+    float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        const float* rec = a.splat + (size_t)idx * GSR_SPLAT_F;
+        const uint32_t off = __float_as_uint(rec[SP_OFFS]);
+        const uint32_t n = a.tiles_touched[idx];
+        const float4* rows = reinterpret_cast<const float4*>(a.grad_rows + (size_t)off * GSR_GROW_F);
+        for (uint32_t t = 0; t < n; t++) {
+            const float4 r0 = rows[3 * t], r1 = rows[3 * t + 1], r2 = rows[3 * t + 2];
+            g[0] += r0.x; g[1] += r0.y; g[2] += r0.z; g[3] += r0.w;
+            g[4] += r1.x; g[5] += r1.y; g[6] += r1.z; g[7] += r1.w;
+            g[8] += r2.x;
+        }
+    }
+    const float dL_dmean2D_x = g[GR_MX], dL_dmean2D_y = g[GR_MY];
+    const float dLc_x = g[GR_CX], dLc_y = g[GR_CY], dLc_w = g[GR_CW];
+    float dL_dcol[3] = {g[GR_R], g[GR_G], g[GR_B]};
+    o_m2[0] = dL_dmean2D_x; o_m2[1] = dL_dmean2D_y; o_m2[2] = 0.f;
+    o_col[0] = dL_dcol[0]; o_col[1] = dL_dcol[1]; o_col[2] = dL_dcol[2];
+    a.dL_dopacity[idx] = g[GR_OPA];
+
+    const float* v = a.viewmatrix;
+    const float* proj = a.projmatrix;
+    const float mx = a.means3D[3 * idx], my = a.means3D[3 * idx + 1], mz = a.means3D[3 * idx + 2];
+
+    // ---- computeCov2DCUDA (backward.cu:144-274) ----
+    const float* cov3D = a.cov3D_in + 6 * (size_t)idx;
+    const float c0 = cov3D[0], c1 = cov3D[1], c2 = cov3D[2], c3 = cov3D[3], c4 = cov3D[4], c5 = cov3D[5];
+    float tx = v[0] * mx + v[4] * my + v[8] * mz + v[12];
+    float ty = v[1] * mx + v[5] * my + v[9] * mz + v[13];
+    const float tz_ = v[2] * mx + v[6] * my + v[10] * mz + v[14];
+    const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+    const float txtz = tx / tz_, tytz = ty / tz_;
+    tx = fminf(limx, fmaxf(-limx, txtz)) * tz_;
+    ty = fminf(limy, fmaxf(-limy, tytz)) * tz_;
+    const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float J00 = h_x / tz_, J02 = -(h_x * tx) / (tz_ * tz_);
+    const float J11 = h_y / tz_, J12 = -(h_y * ty) / (tz_ * tz_);
+    // GLM T[c][r]: T0r / T1r
+    const float T00 = v[0] * J00 + v[1] * 0.0f + v[2] * J02;
+    const float T01 = v[4] * J00 + v[5] * 0.0f + v[6] * J02;
+    const float T02 = v[8] * J00 + v[9] * 0.0f + v[10] * J02;
+    const float T10 = v[0] * 0.0f + v[1] * J11 + v[2] * J12;
+    const float T11 = v[4] * 0.0f + v[5] * J11 + v[6] * J12;
+    const float T12 = v[8] * 0.0f + v[9] * J11 + v[10] * J12;
+    const float A00 = T00 * c0 + T01 * c1 + T02 * c2;
+    const float A10 = T00 * c1 + T01 * c3 + T02 * c4;
+    const float A20 = T00 * c2 + T01 * c4 + T02 * c5;
+    const float A01 = T10 * c0 + T11 * c1 + T12 * c2;
+    const float A11 = T10 * c1 + T11 * c3 + T12 * c4;
+    const float A21 = T10 * c2 + T11 * c4 + T12 * c5;
+    const float ca = (A00 * T00 + A10 * T01 + A20 * T02) + 0.3f;
+    const float cb = A01 * T00 + A11 * T01 + A21 * T02;
+    const float cc = (A01 * T10 + A11 * T11 + A21 * T12) + 0.3f;
+    const float denom = ca * cc - cb * cb;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dcv[6];
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-cc * cc * dLc_x + 2 * cb * cc * dLc_y + (denom - ca * cc) * dLc_w);
+        dL_dc = denom2inv * (-ca * ca * dLc_w + 2 * ca * cb * dLc_y + (denom - ca * cc) * dLc_x);
+        dL_db = denom2inv * 2 * (cb * cc * dLc_x - (denom + 2 * cb * cb) * dLc_y + ca * cb * dLc_w);
+        dcv[0] = (T00 * T00 * dL_da + T00 * T10 * dL_db + T10 * T10 * dL_dc);
+        dcv[3] = (T01 * T01 * dL_da + T01 * T11 * dL_db + T11 * T11 * dL_dc);
+        dcv[5] = (T02 * T02 * dL_da + T02 * T12 * dL_db + T12 * T12 * dL_dc);
+        dcv[1] = 2 * T00 * T01 * dL_da + (T00 * T11 + T01 * T10) * dL_db + 2 * T10 * T11 * dL_dc;
+        dcv[2] = 2 * T00 * T02 * dL_da + (T00 * T12 + T02 * T10) * dL_db + 2 * T10 * T12 * dL_dc;
+        dcv[4] = 2 * T02 * T01 * dL_da + (T01 * T12 + T02 * T11) * dL_db + 2 * T11 * T12 * dL_dc;
+    } else {
+        for (int i = 0; i < 6; i++) dcv[i] = 0;
+    }
+    for (int i = 0; i < 6; i++) o_cov[i] = dcv[i];
+    // Vrk is symmetric: Vrk[0]=(c0,c1,c2), Vrk[1]=(c1,c3,c4), Vrk[2]=(c2,c4,c5)
+    const float dL_dT00 = 2 * (T00 * c0 + T01 * c1 + T02 * c2) * dL_da + (T10 * c0 + T11 * c1 + T12 * c2) * dL_db;
+    const float dL_dT01 = 2 * (T00 * c1 + T01 * c3 + T02 * c4) * dL_da + (T10 * c1 + T11 * c3 + T12 * c4) * dL_db;
+    const float dL_dT02 = 2 * (T00 * c2 + T01 * c4 + T02 * c5) * dL_da + (T10 * c2 + T11 * c4 + T12 * c5) * dL_db;
+    const float dL_dT10 = 2 * (T10 * c0 + T11 * c1 + T12 * c2) * dL_dc + (T00 * c0 + T01 * c1 + T02 * c2) * dL_db;
+    const float dL_dT11 = 2 * (T10 * c1 + T11 * c3 + T12 * c4) * dL_dc + (T00 * c1 + T01 * c3 + T02 * c4) * dL_db;
+    const float dL_dT12 = 2 * (T10 * c2 + T11 * c4 + T12 * c5) * dL_dc + (T00 * c2 + T01 * c4 + T02 * c5) * dL_db;
+    // W[c][r] = v[c + 4r]
+    const float dL_dJ00 = v[0] * dL_dT00 + v[4] * dL_dT01 + v[8] * dL_dT02;
+    const float dL_dJ02 = v[2] * dL_dT00 + v[6] * dL_dT01 + v[10] * dL_dT02;
+    const float dL_dJ11 = v[1] * dL_dT10 + v[5] * dL_dT11 + v[9] * dL_dT12;
+    const float dL_dJ12 = v[2] * dL_dT10 + v[6] * dL_dT11 + v[10] * dL_dT12;
+    const float tz = 1.f / tz_;
+    const float tz2 = tz * tz;
+    const float tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * tx) * tz3 * dL_dJ02 + (2 * h_y * ty) * tz3 * dL_dJ12;
+    float dmean_x = v[0] * dL_dtx + v[1] * dL_dty + v[2] * dL_dtz;
+    float dmean_y = v[4] * dL_dtx + v[5] * dL_dty + v[6] * dL_dtz;
+    float dmean_z = v[8] * dL_dtx + v[9] * dL_dty + v[10] * dL_dtz;
+
+    // ---- preprocessCUDA backward (backward.cu:346-396) ----
+    const float m_homw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+    const float m_w = 1.0f / (m_homw + 0.0000001f);
+    const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+    dmean_x += (proj[0] * m_w - proj[3] * mul1) * dL_dmean2D_x + (proj[1] * m_w - proj[3] * mul2) * dL_dmean2D_y;
+    dmean_y += (proj[4] * m_w - proj[7] * mul1) * dL_dmean2D_x + (proj[5] * m_w - proj[7] * mul2) * dL_dmean2D_y;
+    dmean_z += (proj[8] * m_w - proj[11] * mul1) * dL_dmean2D_x + (proj[9] * m_w - proj[11] * mul2) * dL_dmean2D_y;
+
+    if (a.has_shs) {
+        // computeColorFromSH backward (backward.cu:20-139)
+        const int deg = a.D;
+        const float dox = mx - a.campos[0], doy = my - a.campos[1], doz = mz - a.campos[2];
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox / len, y = doy / len, z = doz / len;
+        const float* sh = a.shs + (size_t)idx * M * 3;
+        float dRGB[3];
+        for (int ch = 0; ch < 3; ch++) dRGB[ch] = dL_dcol[ch] * (a.clamped[3 * idx + ch] ? 0.f : 1.f);
+        float dx_[3] = {0, 0, 0}, dy_[3] = {0, 0, 0}, dz_[3] = {0, 0, 0};
+#define SH(i) sh[3 * (i) + ch]
+#define OUT(i, w) { const float w_ = (w); o_sh[3 * (i)] = w_ * dRGB[0]; o_sh[3 * (i) + 1] = w_ * dRGB[1]; o_sh[3 * (i) + 2] = w_ * dRGB[2]; }
+        OUT(0, bSH_C0);
+        int written = 1;
+        if (deg > 0) {
+            OUT(1, -bSH_C1 * y); OUT(2, bSH_C1 * z); OUT(3, -bSH_C1 * x);
+            written = 4;
+            for (int ch = 0; ch < 3; ch++) {
+                dx_[ch] = -bSH_C1 * SH(3);
+                dy_[ch] = -bSH_C1 * SH(1);
+                dz_[ch] = bSH_C1 * SH(2);
+            }
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                OUT(4, bSH_C2[0] * xy); OUT(5, bSH_C2[1] * yz); OUT(6, bSH_C2[2] * (2.f * zz - xx - yy));
+                OUT(7, bSH_C2[3] * xz); OUT(8, bSH_C2[4] * (xx - yy));
+                written = 9;
+                for (int ch = 0; ch < 3; ch++) {
+                    dx_[ch] += bSH_C2[0] * y * SH(4) + bSH_C2[2] * 2.f * -x * SH(6) + bSH_C2[3] * z * SH(7) + bSH_C2[4] * 2.f * x * SH(8);
+                    dy_[ch] += bSH_C2[0] * x * SH(4) + bSH_C2[1] * z * SH(5) + bSH_C2[2] * 2.f * -y * SH(6) + bSH_C2[4] * 2.f * -y * SH(8);
+                    dz_[ch] += bSH_C2[1] * y * SH(5) + bSH_C2[2] * 2.f * 2.f * z * SH(6) + bSH_C2[3] * x * SH(7);
+                }
+                if (deg > 2) {
+                    OUT(9, bSH_C3[0] * y * (3.f * xx - yy)); OUT(10, bSH_C3[1] * xy * z);
+                    OUT(11, bSH_C3[2] * y * (4.f * zz - xx - yy)); OUT(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                    OUT(13, bSH_C3[4] * x * (4.f * zz - xx - yy)); OUT(14, bSH_C3[5] * z * (xx - yy));
+                    OUT(15, bSH_C3[6] * x * (xx - 3.f * yy));
+                    written = 16;
+                    for (int ch = 0; ch < 3; ch++) {
+                        dx_[ch] += (bSH_C3[0] * SH(9) * 3.f * 2.f * xy + bSH_C3[1] * SH(10) * yz + bSH_C3[2] * SH(11) * -2.f * xy +
+                                    bSH_C3[3] * SH(12) * -3.f * 2.f * xz + bSH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                    bSH_C3[5] * SH(14) * 2.f * xz + bSH_C3[6] * SH(15) * 3.f * (xx - yy));
+                        dy_[ch] += (bSH_C3[0] * SH(9) * 3.f * (xx - yy) + bSH_C3[1] * SH(10) * xz +
+                                    bSH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + bSH_C3[3] * SH(12) * -3.f * 2.f * yz +
+                                    bSH_C3[4] * SH(13) * -2.f * xy + bSH_C3[5] * SH(14) * -2.f * yz +
+                                    bSH_C3[6] * SH(15) * -3.f * 2.f * xy);
+                        dz_[ch] += (bSH_C3[1] * SH(10) * xy + bSH_C3[2] * SH(11) * 4.f * 2.f * yz +
+                                    bSH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + bSH_C3[4] * SH(13) * 4.f * 2.f * xz +
+                                    bSH_C3[5] * SH(14) * (xx - yy));
+                    }
+                }
+            }
+        }
+#undef SH
+#undef OUT
+        for (int i = 3 * written; i < 3 * M; i++) o_sh[i] = 0.f;  // coefficients above the active degree
+        const float ddx = dx_[0] * dRGB[0] + dx_[1] * dRGB[1] + dx_[2] * dRGB[2];
+        const float ddy = dy_[0] * dRGB[0] + dy_[1] * dRGB[1] + dy_[2] * dRGB[2];
+        const float ddz = dz_[0] * dRGB[0] + dz_[1] * dRGB[1] + dz_[2] * dRGB[2];
+        // dnormvdv (auxiliary.h:107-117)
+        const float sum2 = dox * dox + doy * doy + doz * doz;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmean_x += ((+sum2 - dox * dox) * ddx - doy * dox * ddy - doz * dox * ddz) * invsum32;
+        dmean_y += (-dox * doy * ddx + (sum2 - doy * doy) * ddy - doz * doy * ddz) * invsum32;
+        dmean_z += (-dox * doz * ddx - doy * doz * ddy + (sum2 - doz * doz) * ddz) * invsum32;
+    } else {
+        for (int i = 0; i < 3 * M; i++) o_sh[i] = 0.f;
+    }
+    o_m3[0] = dmean_x; o_m3[1] = dmean_y; o_m3[2] = dmean_z;
+
+    if (a.has_scales) {
+        // computeCov3D backward (backward.cu:278-341)
+        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        const float Rq[3][3] = {
+            {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+            {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+            {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+        const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
+                            a.scale_modifier * a.scales[3 * idx + 2]};
+        float Mm[3][3];
+        for (int c = 0; c < 3; c++)
+            for (int k = 0; k < 3; k++) Mm[c][k] = s[k] * Rq[c][k];
+        const float dS[3][3] = {{dcv[0], 0.5f * dcv[1], 0.5f * dcv[2]}, {0.5f * dcv[1], dcv[3], 0.5f * dcv[4]},
+                                {0.5f * dcv[2], 0.5f * dcv[4], dcv[5]}};
+        float dMt[3][3];  // dL_dMt[c][r] = dL_dM[r][c];  dL_dM[c][r] = sum_k (2M)[k][r]*dS[c][k]
+        for (int c = 0; c < 3; c++)
+            for (int rr = 0; rr < 3; rr++)
+                dMt[rr][c] = (2.0f * Mm[0][rr]) * dS[c][0] + (2.0f * Mm[1][rr]) * dS[c][1] + (2.0f * Mm[2][rr]) * dS[c][2];
+        for (int c = 0; c < 3; c++) o_sc[c] = Rq[0][c] * dMt[c][0] + Rq[1][c] * dMt[c][1] + Rq[2][c] * dMt[c][2];
+        for (int c = 0; c < 3; c++)
+            for (int rr = 0; rr < 3; rr++) dMt[c][rr] *= s[c];
+        float4 dq;
+        dq.x = 2 * z * (dMt[0][1] - dMt[1][0]) + 2 * y * (dMt[2][0] - dMt[0][2]) + 2 * x * (dMt[1][2] - dMt[2][1]);
+        dq.y = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
+        dq.z = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
+        dq.w = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+        reinterpret_cast<float4*>(o_rot)[0] = dq;
+    } else {
+        o_sc[0] = 0.f; o_sc[1] = 0.f; o_sc[2] = 0.f;
+        reinterpret_cast<float4*>(o_rot)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+}  // namespace
+
+void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
+{
+    const float h_y = a.H / (2.0f * a.tan_fovy);  // rasterizer_impl.cu:381-382
+    const float h_x = a.W / (2.0f * a.tan_fovx);
+    hipLaunchKernelGGL(gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, h_x, h_y);
+}

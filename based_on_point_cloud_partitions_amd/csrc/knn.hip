@@ -1,0 +1,238 @@
+// distCUDA2 for MI355X: mean squared distance to the 3 nearest other points (exact), used once per
+// sub-scene to initialise Gaussian scales (scene/gaussian_model.py:144).  Replaces SimpleKNN::knn,
+// submodules/simple-knn/simple_knn.cu:185-221.
+//
+// Same pruning idea as the reference (Morton order + AABBs of 1024-point boxes, reject radius from the +-3
+// Morton neighbours) but restructured for wave64 / LDS: a workgroup owns 256 consecutive Morton-sorted queries;
+// for every box that ANY of them cannot reject, the box's points are loaded once, coalesced, into LDS and the
+// interested lanes scan them with broadcast reads.  The reference walks boxes with one divergent thread per
+// point and gathers every candidate from global memory through the index array (simple_knn.cu:147-183).
+// No host round trips (the reference copies min/max back to the host twice, simple_knn.cu:196-200).
+// The result is the exact 3-NN set, so it does not depend on the pruning order; distances are evaluated as
+// dx*dx + dy*dy + dz*dz without contraction, matching the CPU oracle bit for bit.
+#include <float.h>
+#include "common.h"
+
+namespace {
+
+constexpr int BOX = 1024;  // simple_knn.cu:12
+
+struct KnnLayout {
+    size_t partial, minmax, keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, sorted, boxes, bytes;
+    uint32_t sort_blocks, num_boxes, red_blocks;
+};
+
+KnnLayout knn_layout(int P)
+{
+    KnnLayout L;
+    size_t o = 0, p = (size_t)(P > 0 ? P : 1);
+    L.sort_blocks = (uint32_t)((p + GSR_SORT_TILE - 1) / GSR_SORT_TILE);
+    L.num_boxes = (uint32_t)((p + BOX - 1) / BOX);
+    L.red_blocks = (uint32_t)((p + 1023) / 1024);
+    if (L.red_blocks > 1024) L.red_blocks = 1024;
+    L.partial = o; o = gsr_align(o + (size_t)L.red_blocks * 6 * 4);
+    L.minmax = o; o = gsr_align(o + 6 * 4);
+    L.keys_a = o; o = gsr_align(o + p * 8);
+    L.keys_b = o; o = gsr_align(o + p * 8);
+    L.vals_a = o; o = gsr_align(o + p * 4);
+    L.vals_b = o; o = gsr_align(o + p * 4);
+    L.hist_global = o; o = gsr_align(o + 8 * 256 * 4);
+    L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
+    L.sorted = o; o = gsr_align(o + p * 16);
+    L.boxes = o; o = gsr_align(o + (size_t)L.num_boxes * 6 * 4);
+    L.bytes = o;
+    return L;
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// component-wise min / max with init (0,0,0): simple_knn.cu:191-200
+__global__ void __launch_bounds__(256) minmax_partial_kernel(int P, const float* __restrict__ pts, float* __restrict__ partial)
+{
+    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
+        for (int c = 0; c < 3; c++) {
+            const float v = pts[3 * (size_t)i + c];
+            mn[c] = fminf(mn[c], v);
+            mx[c] = fmaxf(mx[c], v);
+        }
+    }
+    __shared__ float red[4][6];
+    for (int c = 0; c < 3; c++) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < 3; c++) { red[threadIdx.x >> 6][c] = mn[c]; red[threadIdx.x >> 6][3 + c] = mx[c]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+__global__ void __launch_bounds__(64) minmax_final_kernel(int nb, const float* __restrict__ partial, float* __restrict__ minmax)
+{
+    if (threadIdx.x < 6) {
+        float v = 0.f;
+        for (int b = 0; b < nb; b++) v = threadIdx.x < 3 ? fminf(v, partial[b * 6 + threadIdx.x]) : fmaxf(v, partial[b * 6 + threadIdx.x]);
+        minmax[threadIdx.x] = v;
+    }
+}
+
+__device__ __forceinline__ uint32_t prep_morton(uint32_t x)  // simple_knn.cu:45-52
+{
+    x = (x | (x << 16)) & 0x030000FF;
+    x = (x | (x << 8)) & 0x0300F00F;
+    x = (x | (x << 4)) & 0x030C30C3;
+    x = (x | (x << 2)) & 0x09249249;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) morton_kernel(int P, const float* __restrict__ pts, const float* __restrict__ minmax,
+                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    // simple_knn.cu:54-61
+    const uint32_t mxc = prep_morton((uint32_t)(((x - minmax[0]) / (minmax[3] - minmax[0])) * 1023.0f));
+    const uint32_t myc = prep_morton((uint32_t)(((y - minmax[1]) / (minmax[4] - minmax[1])) * 1023.0f));
+    const uint32_t mzc = prep_morton((uint32_t)(((z - minmax[2]) / (minmax[5] - minmax[2])) * 1023.0f));
+    keys[i] = (uint64_t)(mxc | (myc << 1) | (mzc << 2));
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) gather_sorted_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
+                                                            float4* __restrict__ sorted)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t o = order[i];
+    sorted[i] = make_float4(pts[3 * (size_t)o], pts[3 * (size_t)o + 1], pts[3 * (size_t)o + 2], __uint_as_float(o));
+}
+
+// AABB of each run of 1024 sorted points (boxMinMax, simple_knn.cu:78-117)
+__global__ void __launch_bounds__(256) box_minmax_kernel(int P, const float4* __restrict__ sorted, float* __restrict__ boxes)
+{
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    const int base = blockIdx.x * BOX;
+    for (int k = threadIdx.x; k < BOX; k += 256) {
+        const int i = base + k;
+        if (i < P) {
+            const float4 p = sorted[i];
+            mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        }
+    }
+    __shared__ float red[4][6];
+    for (int c = 0; c < 3; c++) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < 3; c++) { red[threadIdx.x >> 6][c] = mn[c]; red[threadIdx.x >> 6][3 + c] = mx[c]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        boxes[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__device__ __forceinline__ void update3(float qx, float qy, float qz, float cx, float cy, float cz, float& b0, float& b1, float& b2)
+{
+    // updateKBest<3>, simple_knn.cu:131-145
+    const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
+    float dist = dx * dx + dy * dy + dz * dz;
+    if (b0 > dist) { const float t = b0; b0 = dist; dist = t; }
+    if (b1 > dist) { const float t = b1; b1 = dist; dist = t; }
+    if (b2 > dist) { b2 = dist; }
+}
+
+__global__ void __launch_bounds__(256) knn_kernel(int P, uint32_t num_boxes, const float4* __restrict__ sorted,
+                                                  const float* __restrict__ boxes, float* __restrict__ out)
+{
+    __shared__ float s_x[BOX], s_y[BOX], s_z[BOX];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = idx < P;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    uint32_t orig = 0;
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    if (valid) {
+        const float4 q = sorted[idx];
+        qx = q.x; qy = q.y; qz = q.z; orig = __float_as_uint(q.w);
+        // seed the reject radius from the +-3 Morton neighbours (simple_knn.cu:156-163)
+        const int lo = max(0, idx - 3), hi = min(P - 1, idx + 3);
+        for (int i = lo; i <= hi; i++) {
+            if (i == idx) continue;
+            const float4 c = sorted[i];
+            update3(qx, qy, qz, c.x, c.y, c.z, b0, b1, b2);
+        }
+    }
+    const float reject = b2;
+    b0 = FLT_MAX; b1 = FLT_MAX; b2 = FLT_MAX;
+    for (uint32_t b = 0; b < num_boxes; b++) {
+        // distBoxPoint, simple_knn.cu:119-129
+        const float mnx = boxes[b * 6], mny = boxes[b * 6 + 1], mnz = boxes[b * 6 + 2];
+        const float mxx = boxes[b * 6 + 3], mxy = boxes[b * 6 + 4], mxz = boxes[b * 6 + 5];
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        if (qx < mnx || qx > mxx) ddx = fminf(fabsf(qx - mnx), fabsf(qx - mxx));
+        if (qy < mny || qy > mxy) ddy = fminf(fabsf(qy - mny), fabsf(qy - mxy));
+        if (qz < mnz || qz > mxz) ddz = fminf(fabsf(qz - mnz), fabsf(qz - mxz));
+        const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
+        const bool want = valid && !(dist > reject || dist > b2);
+        if (!__syncthreads_or(want)) continue;
+        const int base = (int)b * BOX;
+        const int cnt = min(BOX, P - base);
+        for (int k = threadIdx.x; k < cnt; k += 256) {
+            const float4 c = sorted[base + k];
+            s_x[k] = c.x; s_y[k] = c.y; s_z[k] = c.z;
+        }
+        __syncthreads();
+        if (want) {
+            const int self = idx - base;  // position of this query inside the box, if it is in it
+            for (int k = 0; k < cnt; k++) {
+                if (k == self) continue;
+                update3(qx, qy, qz, s_x[k], s_y[k], s_z[k], b0, b1, b2);
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) out[orig] = (b0 + b1 + b2) / 3.0f;
+}
+
+}  // namespace
+
+size_t gsr_knn_scratch_layout_bytes(int P) { return knn_layout(P).bytes; }
+
+int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s)
+{
+    if (P <= 0) return 0;
+    const KnnLayout L = knn_layout(P);
+    if (scratch_bytes < L.bytes) return -1;
+    char* base = (char*)scratch;
+    float* partial = (float*)(base + L.partial);
+    float* minmax = (float*)(base + L.minmax);
+    uint64_t* ka = (uint64_t*)(base + L.keys_a);
+    uint64_t* kb = (uint64_t*)(base + L.keys_b);
+    uint32_t* va = (uint32_t*)(base + L.vals_a);
+    uint32_t* vb = (uint32_t*)(base + L.vals_b);
+    float4* sorted = (float4*)(base + L.sorted);
+    float* boxes = (float*)(base + L.boxes);
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(L.red_blocks), dim3(256), 0, s, P, points, partial);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, s, (int)L.red_blocks, partial, minmax);
+    hipLaunchKernelGGL(morton_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, minmax, ka, va);
+    const int in_b = gsr_launch_radix_sort(ka, kb, va, vb, (uint32_t)P, 32, (uint32_t*)(base + L.hist_global),
+                                           (uint32_t*)(base + L.hist_blocks), L.sort_blocks, s);
+    const uint32_t* order = in_b ? vb : va;
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, order, sorted);
+    hipLaunchKernelGGL(box_minmax_kernel, dim3(L.num_boxes), dim3(256), 0, s, P, sorted, boxes);
+    hipLaunchKernelGGL(knn_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, L.num_boxes, sorted, boxes, out);
+    return 0;
+}

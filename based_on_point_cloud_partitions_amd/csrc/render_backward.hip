@@ -1,0 +1,203 @@
+// Backward of the alpha compositing, one 16x16 tile per 256-thread workgroup (4 wave64s).
+// Replaces renderCUDA, cuda_rasterizer/backward.cu:399-557.
+//
+// The reference issues 9 global float atomicAdds per contributing (pixel, Gaussian) pair
+// (backward.cu:523,545-554).  On MI355X global float atomics top out near 1.3 TB/s chip-wide and collapse
+// when lanes scatter, so this kernel never uses them: the 9 partial sums of a list entry are reduced across
+// the 64 pixels of a wave with DPP adds (fixed tree), the four waves' results are combined through LDS in
+// wave order, and every list entry writes ONE 48-byte gradient row with plain stores.  Rows are addressed
+// by the Gaussian's emission slot (exclusive instance offset + position of this tile in its rectangle), so
+// the rows of one Gaussian are contiguous and the per-Gaussian kernel sums them in a fixed order:
+// gradients are bitwise reproducible run to run, unlike the reference's.
+//
+// Traversal is back to front from the tile's largest n_contrib (entries behind it contribute to no pixel,
+// backward.cu:480-482); alpha / G are recomputed with exactly the forward's arithmetic.
+#include "common.h"
+
+namespace {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(t);
+}
+
+// Sum over the 64 lanes of a wave; the total is valid in lane 63.
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);  // row_mirror   -> every lane holds its row-of-16 total
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3 += rows 0,2
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3 += lanes 0..31
+    return v;
+}
+
+constexpr int NV = 9;                   // partial sums per list entry
+constexpr int ACC_STRIDE = 256 * NV;    // floats per wave
+
+__global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float* __restrict__ splat, const float* __restrict__ bg,
+                                                              const float* __restrict__ final_Ts,
+                                                              const uint32_t* __restrict__ n_contrib,
+                                                              const float* __restrict__ dL_dpixels, float* __restrict__ grad_rows)
+{
+    __shared__ float4 s_a[256];  // mx, my, conic.x, conic.y
+    __shared__ float4 s_b[256];  // conic.z, opacity, pthr, row index (uint bits)
+    __shared__ float4 s_c[256];  // r, g, b, -
+    __shared__ __attribute__((aligned(16))) float s_acc[4 * ACC_STRIDE];
+    __shared__ uint32_t s_max[4];
+
+    const uint32_t tile = blockIdx.y * gx + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t pix_x = blockIdx.x * GSR_TILE_X + (tid & 15), pix_y = blockIdx.y * GSR_TILE_Y + (tid >> 4);
+    const bool inside = pix_x < (uint32_t)W && pix_y < (uint32_t)H;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const size_t plane = (size_t)H * W;
+    const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const uint32_t total = r1 - r0;
+    if (total == 0) return;
+
+    const float T_final = inside ? final_Ts[pix_id] : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
+    float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
+    if (inside) { dL0 = dL_dpixels[pix_id]; dL1 = dL_dpixels[plane + pix_id]; dL2 = dL_dpixels[2 * plane + pix_id]; }
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const float bg_dot = ((0.f + bg0 * dL0) + bg1 * dL1) + bg2 * dL2;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    // largest n_contrib of the tile = number of list entries that matter to any pixel
+    uint32_t m = last_contributor;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    const uint32_t hi = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+    float accum0 = 0.f, accum1 = 0.f, accum2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    float* my_acc = s_acc + wave * ACC_STRIDE;
+    const int rounds = (int)((hi + 255) / 256);
+
+    for (int i = 0; i < rounds; i++) {
+        __syncthreads();  // previous batch fully flushed
+        const uint32_t progress = (uint32_t)i * 256 + tid;
+        if (progress < hi) {
+            const uint32_t k = hi - 1 - progress;
+            const uint32_t id = point_list[r0 + k];
+            const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            uint32_t mnx, mny, mxx, mxy;
+            gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
+            const uint32_t row = __float_as_uint(q2.w) + (blockIdx.y - mny) * (mxx - mnx) + (blockIdx.x - mnx);
+            const float pthr = __logf(1.0f / (255.0f * q1.y)) - 1e-3f;
+            s_a[tid] = q0;
+            s_b[tid] = make_float4(q1.x, q1.y, pthr, __uint_as_float(row));
+            s_c[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
+        }
+        {   // zero this wave's accumulators (9 x float4 per lane)
+            float4* z = reinterpret_cast<float4*>(my_acc);
+#pragma unroll
+            for (int t = 0; t < ACC_STRIDE / 4 / 64; t++) z[t * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        const int nb = (int)min(256u, hi - (uint32_t)i * 256);
+        for (int j = 0; j < nb; j++) {
+            const uint32_t kidx = hi - 1 - ((uint32_t)i * 256 + j);
+            bool contrib = false;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
+            if (kidx < last_contributor) {
+                const float4 a = s_a[j];
+                const float4 b = s_b[j];
+                const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+                // identical to the forward (CONTRACT-FMA)
+                const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
+                const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
+                if (power <= 0.0f && !(power < b.z)) {
+                    const float G = gsr_expf(power);
+                    const float alpha = fminf(0.99f, b.y * G);
+                    if (alpha >= 1.0f / 255.0f) {
+                        contrib = true;
+                        const float4 c = s_c[j];
+                        const float inv = 1.0f / (1.f - alpha);
+                        T = T * inv;  // T / (1 - alpha), backward.cu:502
+                        const float dchannel_dcolor = alpha * T;
+                        const float oma = 1.f - last_alpha;
+                        accum0 = last_alpha * lc0 + oma * accum0;
+                        accum1 = last_alpha * lc1 + oma * accum1;
+                        accum2 = last_alpha * lc2 + oma * accum2;
+                        lc0 = c.x; lc1 = c.y; lc2 = c.z;
+                        float dL_dalpha = (c.x - accum0) * dL0 + (c.y - accum1) * dL1 + (c.z - accum2) * dL2;
+                        v6 = dchannel_dcolor * dL0;
+                        v7 = dchannel_dcolor * dL1;
+                        v8 = dchannel_dcolor * dL2;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final * inv) * bg_dot;
+                        const float dL_dG = b.y * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                        const float dG_ddely = -gdy * b.x - gdx * a.w;
+                        v0 = dL_dG * dG_ddelx * ddelx_dx;
+                        v1 = dL_dG * dG_ddely * ddely_dy;
+                        v2 = -0.5f * gdx * dx * dL_dG;
+                        v3 = -0.5f * gdx * dy * dL_dG;
+                        v4 = -0.5f * gdy * dy * dL_dG;
+                        v5 = G * dL_dalpha;
+                    }
+                }
+            }
+            if (__ballot(contrib) != 0ull) {  // wave-uniform
+                v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
+                v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
+                v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
+                if (lane == 63) {
+                    float* o = my_acc + j * NV;
+                    o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7; o[8] = v8;
+                }
+            }
+        }
+        __syncthreads();
+        // flush: entry `tid` of the batch -> one 48-byte row, waves summed in fixed order
+        if (tid < nb) {
+            float r[NV];
+#pragma unroll
+            for (int t = 0; t < NV; t++) {
+                r[t] = ((s_acc[tid * NV + t] + s_acc[ACC_STRIDE + tid * NV + t]) + s_acc[2 * ACC_STRIDE + tid * NV + t]) +
+                       s_acc[3 * ACC_STRIDE + tid * NV + t];
+            }
+            const uint32_t row = __float_as_uint(s_b[tid].w);
+            float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
+            o[0] = make_float4(r[0], r[1], r[2], r[3]);
+            o[1] = make_float4(r[4], r[5], r[6], r[7]);
+            o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+        }
+    }
+    // list entries behind every pixel's last contributor: zero rows
+    for (uint32_t e = hi + tid; e < total; e += 256) {
+        const uint32_t id = point_list[r0 + e];
+        const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
+        const float4 q0 = rec[0], q2 = rec[2];
+        uint32_t mnx, mny, mxx, mxy;
+        gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
+        const uint32_t row = __float_as_uint(q2.w) + (blockIdx.y - mny) * (mxx - mnx) + (blockIdx.x - mnx);
+        float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        o[0] = z; o[1] = z; o[2] = z;
+    }
+}
+
+}  // namespace
+
+void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
+                                const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
+                                float* grad_rows, hipStream_t s)
+{
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    hipLaunchKernelGGL(render_backward_kernel, dim3(gx, gy), dim3(256), 0, s, W, H, gx, gy, ranges, point_list, splat, bg, final_T,
+                       n_contrib, dL_dpix, grad_rows);
+}

@@ -1,0 +1,112 @@
+// Front-to-back alpha compositing, one 16x16 tile per 256-thread workgroup (4 wave64s, each a 16x4 pixel strip).
+// Replaces renderCUDA, cuda_rasterizer/forward.cu:261-374.
+//
+// Per batch of 256 list entries the workgroup gathers each splat's packed 48-byte record into LDS
+// (three 16-byte loads per lane) and every wave then walks the batch reading the entry with wave-uniform
+// (broadcast) LDS reads.  A wave leaves the walk as soon as all of its 64 pixels are done, the workgroup
+// stops when all four have (the reference's __syncthreads_count early exit, forward.cu:301-304).
+//
+// Arithmetic contract with the CPU oracle: power / colour accumulation use the explicit fmaf pairs
+// below ("CONTRACT-FMA"), exp is gsr_expf -> final_T, n_contrib and out_color are bit-identical.
+// The `pthr` test is a pure shortcut: power < ln(1/(255*opacity)) - 1e-3 implies alpha < 1/255 for any
+// exp accurate to 1e-6, so skipping the exp there cannot change a decision.
+#include "common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, const uint32_t* __restrict__ ranges,
+                                                             const uint32_t* __restrict__ point_list,
+                                                             const float* __restrict__ splat, const float* __restrict__ bg,
+                                                             float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                             float* __restrict__ out_color)
+{
+    __shared__ float4 s_a[256];  // mx, my, conic.x, conic.y
+    __shared__ float4 s_b[256];  // conic.z, opacity, pthr, -
+    __shared__ float4 s_c[256];  // r, g, b, -
+    __shared__ int s_done[4];
+
+    const uint32_t tile = blockIdx.y * gx + blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t pix_x = blockIdx.x * GSR_TILE_X + (tid & 15), pix_y = blockIdx.y * GSR_TILE_Y + (tid >> 4);
+    const bool inside = pix_x < (uint32_t)W && pix_y < (uint32_t)H;
+    const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const int total = (int)(r1 - r0);
+    const int rounds = (total + 255) / 256;
+
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t contributor = 0, last_contributor = 0;
+    int toDo = total;
+
+    for (int i = 0; i < rounds; i++, toDo -= 256) {
+        // workgroup-wide early exit
+        const bool wave_done = __ballot(!done) == 0ull;
+        if ((tid & 63) == 0) s_done[wave] = wave_done;
+        __syncthreads();
+        if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
+        const int progress = i * 256 + tid;
+        if (progress < total) {
+            const uint32_t id = point_list[r0 + progress];
+            const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            // conservative skip threshold on `power` (see header); NaN (opacity <= 0) never skips
+            const float pthr = __logf(1.0f / (255.0f * q1.y)) - 1e-3f;
+            s_a[tid] = q0;
+            s_b[tid] = make_float4(q1.x, q1.y, pthr, 0.f);
+            s_c[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
+        }
+        __syncthreads();
+        if (!wave_done) {
+            const int nb = min(256, toDo);
+            for (int j = 0; j < nb; j++) {
+                if (__ballot(!done) == 0ull) break;
+                if (!done) {
+                    contributor++;
+                    const float4 a = s_a[j];
+                    const float4 b = s_b[j];
+                    const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+                    // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
+                    const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
+                    const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
+                    if (power <= 0.0f && !(power < b.z)) {
+                        const float alpha = fminf(0.99f, b.y * gsr_expf(power));
+                        if (alpha >= 1.0f / 255.0f) {
+                            const float test_T = T * (1.0f - alpha);
+                            if (test_T < 0.0001f) {
+                                done = true;
+                            } else {
+                                const float4 c = s_c[j];
+                                // CONTRACT-FMA: C += (f*alpha)*T
+                                C0 = __builtin_fmaf(c.x * alpha, T, C0);
+                                C1 = __builtin_fmaf(c.y * alpha, T, C1);
+                                C2 = __builtin_fmaf(c.z * alpha, T, C2);
+                                T = test_T;
+                                last_contributor = contributor;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (inside) {
+        const size_t pix_id = (size_t)W * pix_y + pix_x;
+        const size_t plane = (size_t)H * W;
+        final_T[pix_id] = T;
+        n_contrib[pix_id] = last_contributor;
+        out_color[pix_id] = C0 + T * bg[0];
+        out_color[plane + pix_id] = C1 + T * bg[1];
+        out_color[2 * plane + pix_id] = C2 + T * bg[2];
+    }
+}
+
+}  // namespace
+
+void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
+                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, hipStream_t s)
+{
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    hipLaunchKernelGGL(render_forward_kernel, dim3(gx, gy), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg, final_T,
+                       n_contrib, out_color);
+}

@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: raster steps (GaussianRasterizer forward + backward) per second.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one camera of the partition: frustum cull + covariance projection +
+SH colour, tile binning (prefix sum, key emission, 64-bit radix sort, tile ranges), alpha compositing, and the
+full backward for a fixed synthetic dL/dcolor -- what train.py:107 + :118 spend in the rasterizer.
+Workload at N = 1: BASELINE.json configs[1] (one partition of 500,000 random-init Gaussians, 1920x1080, SH degree 3,
+16 cameras on a ring); at N > 1 every rank owns its own 500k-Gaussian partition (weak scaling, no data-path
+collective: the reference trains partitions independently, auto_train.py:22-51).
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from based_on_point_cloud_partitions_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib  # noqa: E402
+from based_on_point_cloud_partitions_amd import synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def stage_bytes(P, V, R, N, key_bits, K=16):
+    """ALGORITHMIC bytes per launch of each stage (SURVEY.md §8d / DESIGN.md): defined by the reference's data flow."""
+    passes = (key_bits + 7) // 8
+    return {
+        "preprocess": 20 * P + (32 + 12 * K + 67) * V,
+        "scan": 8 * P,
+        "emit_keys": 8 * P + 12 * V + 12 * R,
+        "radix_sort": 8 * R + 24 * R * passes,
+        "tile_ranges": 8 * R,
+        "render_forward": 40 * R + 20 * N,
+        "render_backward": 76 * R + 20 * N,
+        "gaussian_backward": 308 * P + (88 + 143 + 24 * K) * V,
+    }
+
+
+def higher_msb(n):
+    msb, step = 16, 16
+    while step > 1:
+        step //= 2
+        msb = msb + step if (n >> msb) else msb - step
+    if n >> msb:
+        msb += 1
+    return msb
+
+
+def cpu_baseline(cfg, g, cam, dL):
+    """The oracle (a CPU port of the reference algorithm; the reference has no CPU path) on ONE step of the same workload."""
+    from oracle import oracle
+
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    t0 = time.perf_counter()
+    st = oracle.forward(g.xyz.numpy(), g.opacities.numpy(), shs=g.shs.numpy(), scales=g.scales.numpy(),
+                        rotations=g.rotations.numpy(), viewmatrix=cam.world_view_transform.numpy(),
+                        projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
+                        bg=np.zeros(3, np.float32), W=cam.image_width, H=cam.image_height, tanfovx=cam.tanfovx,
+                        tanfovy=cam.tanfovy, sh_degree=3)
+    t1 = time.perf_counter()
+    oracle.backward(st, dL)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"1 raster step (camera 0 of the {cfg['P']}-Gaussian {cfg['W']}x{cfg['H']} workload): "
+                      f"forward {t1 - t0:.2f} s + backward {t2 - t1:.2f} s, OpenMP over Gaussians/tiles"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="cfg2", choices=sorted(syn.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timers", action="store_true", help="time the region without per-stage HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = syn.CONFIGS[args.config]
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    if world == 1:
+        g = syn.make_gaussians(P, seed=0)
+        centre = (0.0, 0.0, 0.0)
+    else:
+        g, centre, _box = syn.make_partition(rank, world, P, seed=0)
+    cams = syn.ring_cameras(cfg["cameras"], W, H, cfg["focal"], center=centre)
+    dL_cpu = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
+    dL = dL_cpu.to(dev)
+    bg = torch.zeros(3, device=dev)
+    xyz = g.xyz.to(dev).requires_grad_(True)
+    scales = g.scales.to(dev).requires_grad_(True)
+    rots = g.rotations.to(dev).requires_grad_(True)
+    opac = g.opacities.to(dev).requires_grad_(True)
+    shs = g.shs.to(dev).requires_grad_(True)
+    params = [xyz, scales, rots, opac, shs]
+    rasterizers = [GaussianRasterizer(GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=bg, scale_modifier=1.0,
+        viewmatrix=c.world_view_transform.to(dev), projmatrix=c.full_proj_transform.to(dev), sh_degree=3,
+        campos=c.camera_center.to(dev), prefiltered=False, debug=False)) for c in cams]
+
+    def step(i):
+        r = rasterizers[i % len(rasterizers)]
+        screenspace = torch.zeros_like(xyz, requires_grad=True)  # receives dL/dmeans2D (gaussian_renderer/__init__.py:26)
+        image, radii = r(means3D=xyz, means2D=screenspace, opacities=opac, shs=shs, scales=scales, rotations=rots)
+        image.backward(dL)
+        for p in params:
+            p.grad = None
+        return radii
+
+    # untimed statistics pass: V and R per camera (every byte / flop figure is a function of them)
+    stats = []
+    with torch.no_grad():
+        from based_on_point_cloud_partitions_amd import rasterizer as rz
+        e = torch.Tensor([])
+        for c, r in zip(cams, rasterizers):
+            s = r.raster_settings
+            R, _, radii, gb, bb, ib = rz.rasterize_gaussians_forward(s.bg, xyz, e, opac, scales, rots, 1.0, e, s.viewmatrix,
+                                                                     s.projmatrix, s.tanfovx, s.tanfovy, H, W, shs, 3, s.campos,
+                                                                     False, False)
+            ex = rz.debug_export(P, R, W, H, gb, bb, ib)
+            ln = (ex["ranges"][:, 1] - ex["ranges"][:, 0]).float()
+            stats.append(dict(V=int((radii > 0).sum()), R=int(R), tile_mean=float(ln.mean()), tile_max=int(ln.max()),
+                              n_contrib_mean=float(ex["n_contrib"].float().mean())))
+            del gb, bb, ib, ex
+    torch.cuda.empty_cache()
+
+    for i in range(args.warmup):
+        step(i)
+    use_timers = not args.no_stage_timers
+    _lib.profile_enable(False)
+    _lib.profile_collect()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    _lib.profile_enable(use_timers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    stage = _lib.profile_collect() if use_timers else {}
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        used = [stats[(args.warmup + i) % len(stats)] for i in range(args.steps)]
+        V = float(np.mean([u["V"] for u in used]))
+        R = float(np.mean([u["R"] for u in used]))
+        N = W * H
+        key_bits = 32 + higher_msb(((W + 15) // 16) * ((H + 15) // 16))
+        sb = stage_bytes(P, V, R, N, key_bits)
+        step_bytes = float(sum(sb.values()))
+        ms_per_step = 1e3 * elapsed / args.steps
+        kernels = []
+        for name, (ms, n) in stage.items():
+            if n == 0:
+                continue
+            avg_ms = ms / n
+            kernels.append({"kernel": name, "avg_ms": round(avg_ms, 4), "launches": n,
+                            "algorithmic_MB": round(sb[name] / 1e6, 2),
+                            "achieved_GBs": round(sb[name] / 1e9 / (avg_ms * 1e-3), 1)})
+        kernels.sort(key=lambda k: -k["avg_ms"])
+        roofline = None
+        if kernels:
+            d = kernels[0]
+            roofline = {"kernel": d["kernel"], "bound": "hbm", "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(d["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_ms": d["avg_ms"], "algorithmic_bytes": int(sb[d["kernel"]]),
+                        "note": "dominant kernel by time; blend kernels are VALU/LDS-bound pair loops (DESIGN.md), so their HBM "
+                                "fraction is low by construction -- see roofline_kernels for the streaming stages and "
+                                "roofline_step for the whole step"}
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    roofline["traffic"] = json.load(open(pmc)).get(d["kernel"])
+                except Exception:
+                    pass
+        fwd_ms = sum(k["avg_ms"] for k in kernels if k["kernel"] in
+                     ("preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges", "render_forward"))
+        out = {
+            "metric": "train iters/sec (rasterizer forward+backward step), 500k-Gaussian partition @1080p",
+            "value": round(world * args.steps / elapsed, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: one partition of {P} random-init Gaussians per GPU, {W}x{H}, SH degree 3, "
+                                   f"{len(cams)} ring cameras, fixed N(0,1) dL/dcolor", "gaussians_per_gpu": P,
+                       "image": [W, H], "sh_degree": 3, "parallelism": f"{world} independent partition(s), 1 per GPU"},
+            "workload_stats": {"P": P, "V_mean": round(V, 1), "R_mean": round(R, 1), "N": N, "key_bits": key_bits,
+                               "tile_list_mean": round(float(np.mean([u["tile_mean"] for u in used])), 1),
+                               "tile_list_max": int(max(u["tile_max"] for u in used)),
+                               "n_contrib_mean": round(float(np.mean([u["n_contrib_mean"] for u in used])), 1)},
+            "rendered_mpix_per_s_fwd": round(world * N / 1e6 / (fwd_ms * 1e-3), 1) if fwd_ms > 0 else None,
+            "roofline": roofline,
+            "roofline_step": {"bound": "hbm", "algorithmic_bytes": int(step_bytes),
+                              "achieved": round(step_bytes / 1e9 / (ms_per_step * 1e-3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(step_bytes / 1e9 / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 4)},
+            "roofline_kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, g, cams[0], dL_cpu.numpy())
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

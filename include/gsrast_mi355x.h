@@ -1,0 +1,109 @@
+/*
+ * gsrast_mi355x.h -- C ABI of the MI355X (gfx950) Gaussian-splat rasterizer + kNN-init library
+ * (libgsrast_mi355x.so).  This is the drop-in boundary for the ONE hot path of
+ * 92401/Based-on-point-cloud-partitions: it replaces the pybind11/libtorch functions of
+ * submodules/diff-gaussian-rasterization (rasterize_points.h:18-67, ext.cpp:15-19) and
+ * submodules/simple-knn (spatial.h, ext.cpp:15-17).  Plain pointers and sizes only, no torch types.
+ *
+ * Conventions (identical to the reference):
+ *  - every pointer is a DEVICE pointer to contiguous float32 / int32 / uint8 data unless marked "host";
+ *  - optional inputs are passed as NULL (the reference passes empty tensors, rasterize_points.cu:94-111);
+ *    exactly one of {shs, colors_precomp} and one of {scales+rotations, cov3D_precomp} must be non-NULL;
+ *  - shs is [P][M][3], out_color is [3][H][W], viewmatrix / projmatrix are the transposed 4x4 matrices
+ *    flattened row-major (element [4*c + r] = row r, column c), campos / bg are 3 floats on the device;
+ *  - `stream` is a hipStream_t (NULL = default stream); all work is enqueued on it;
+ *  - the three state buffers are opaque, owned by the caller, and must be kept alive between forward and
+ *    backward (the reference does the same through ctx.save_for_backward, __init__.py:92-97).
+ *  - return value: 0 on success, negative on error; gsr_last_error() describes the last error of the
+ *    calling thread (the reference throws std::runtime_error / AT_ERROR).
+ *
+ * The forward is two-phase because the number of (Gaussian, tile) instances R is only known after the
+ * per-Gaussian stage (the reference resizes its binning buffer through a std::function callback instead,
+ * rasterize_points.cu:27-33, rasterizer_impl.cu:281-285).
+ */
+#ifndef GSRAST_MI355X_H
+#define GSRAST_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+int gsr_abi_version(void);
+const char* gsr_last_error(void);
+
+/* Sizes in bytes of the opaque state buffers (required<GeometryState/ImageState/BinningState>,
+ * rasterizer_impl.h:67-73) and of the backward scratch (one 48-byte gradient row per instance). */
+size_t gsr_geometry_bytes(int P);
+size_t gsr_image_bytes(int W, int H);
+size_t gsr_binning_bytes(int64_t R);
+size_t gsr_backward_scratch_bytes(int64_t R);
+
+/* Phase 1 of CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:198-285): frustum cull, covariance
+ * projection, SH colour, tiles_touched and its prefix sum.  Writes radii[P] and *num_rendered_host (host
+ * pointer; the call synchronises `stream` once to read it, like the reference's cudaMemcpy at :281). */
+int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                         const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                         const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                         int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* geom_buffer,
+                         size_t geom_bytes, int64_t* num_rendered_host, void* stream);
+
+/* Phase 2 (rasterizer_impl.cu:287-336): key emission, 64-bit radix sort, tile ranges, alpha compositing. */
+int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, void* geom_buffer, size_t geom_bytes,
+                       void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes,
+                       float* out_color, void* stream);
+
+/* CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:340-434) + the zero-initialised outputs of
+ * RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-159): every output element is written.
+ * Outputs: dL_dmeans2D[P][3], dL_dcolors[P][3], dL_dopacity[P], dL_dmeans3D[P][3], dL_dcov3D[P][6],
+ * dL_dsh[P][M][3], dL_dscales[P][3], dL_drotations[P][4]. */
+int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
+                 size_t geom_bytes, const void* binning_buffer, size_t binning_bytes, const void* image_buffer,
+                 size_t image_bytes, void* scratch, size_t scratch_bytes, const float* dL_dpix, float* dL_dmeans2D,
+                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscales, float* dL_drotations, void* stream);
+
+/* markVisible (rasterize_points.cu:198-217): present[i] = 1 iff the point passes the near-plane test. */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream);
+
+/* distCUDA2 (submodules/simple-knn/spatial.cu:15-26): out[i] = mean squared distance from point i to its 3
+ * nearest other points.  points is [P][3]. */
+size_t gsr_knn_scratch_bytes(int P);
+int gsr_knn_mean_dist2(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Test/inspection hook: copies the intermediates held in the opaque buffers into plain arrays (any output may
+ * be NULL).  means2D[P][2], depths[P], conic_opacity[P][4], rgb[P][3], cov3D[P][6], clamped[P][3],
+ * tiles_touched[P], point_offsets[P], keys_sorted[R], point_list[R], ranges[T][2], final_T[H*W], n_contrib[H*W]. */
+int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, const void* binning_buffer,
+                     const void* image_buffer, float* means2D, float* depths, float* conic_opacity, float* rgb, float* cov3D,
+                     uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_offsets, uint64_t* keys_sorted,
+                     uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, void* stream);
+
+/* Stand-alone stable LSD radix sort of (u64,u32) pairs on bits [0,end_bit) (the binning sort, exported for
+ * tests).  Returns 0 if the result is in (keys_a, vals_a), 1 if in (keys_b, vals_b), negative on error.
+ * scratch must hold gsr_sort_scratch_bytes(n) bytes. */
+size_t gsr_sort_scratch_bytes(int64_t n);
+int gsr_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t n, int end_bit,
+                   void* scratch, size_t scratch_bytes, void* stream);
+
+/* Optional per-stage timing (bench.py): when enabled, every stage launched through this library is bracketed by
+ * HIP events on the caller's stream; gsr_profile_collect() waits for them, sums elapsed ms and launch counts per
+ * stage (arrays of nstages >= GSR_NUM_STAGES) and resets the log. */
+enum {
+    GSR_STAGE_PREPROCESS = 0, GSR_STAGE_SCAN = 1, GSR_STAGE_EMIT = 2, GSR_STAGE_SORT = 3, GSR_STAGE_RANGES = 4,
+    GSR_STAGE_RENDER_FWD = 5, GSR_STAGE_RENDER_BWD = 6, GSR_STAGE_GAUSS_BWD = 7, GSR_NUM_STAGES = 8
+};
+void gsr_profile_enable(int on);
+int gsr_profile_collect(double* ms_per_stage, int64_t* launches_per_stage, int nstages);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -30,7 +30,107 @@ def oracle_forward(g, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, scale_modifier=1.0, 
                           tanfovy=cam.tanfovy, sh_degree=sh_degree, scale_modifier=scale_modifier, **kw)
 
 
+def snapshot_scene(fx):
+    """Inputs stored in tests/golden/oracle_snapshot.npz -> (gaussians, camera, bg)."""
+    g = syn.SyntheticGaussians(torch.tensor(fx["xyz"]), torch.tensor(fx["scales"]), torch.tensor(fx["rotations"]),
+                               torch.tensor(fx["opacities"]), torch.tensor(fx["shs"].astype(np.float32)))
+    W, H, tx, ty, fvx, fvy = fx["cam"]
+    cam = syn.SyntheticCamera(int(W), int(H), float(fvx), float(fvy), float(tx), float(ty), torch.tensor(fx["viewmatrix"]),
+                              torch.tensor(fx["projmatrix"]), torch.tensor(fx["campos"]))
+    return g, cam, tuple(float(v) for v in fx["bg"])
+
+
 def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12)) if a.size else 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# product side (HIP through the C ABI).  Everything below needs a GPU.
+# ---------------------------------------------------------------------------------------------
+def hip_settings(cam, bg, sh_degree, scale_modifier=1.0, device="cuda", debug=False):
+    from based_on_point_cloud_partitions_amd import GaussianRasterizationSettings
+
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=torch.tensor(bg, dtype=torch.float32, device=device), scale_modifier=scale_modifier,
+        viewmatrix=cam.world_view_transform.to(device), projmatrix=cam.full_proj_transform.to(device), sh_degree=sh_degree,
+        campos=cam.camera_center.to(device), prefiltered=False, debug=debug)
+
+
+def hip_forward_raw(g, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, scale_modifier=1.0, colors_precomp=None, cov3D_precomp=None,
+                    device="cuda"):
+    """Calls the `_C.rasterize_gaussians` counterpart and exports the intermediates."""
+    from based_on_point_cloud_partitions_amd import rasterizer as rz
+
+    e = torch.Tensor([])
+    d = lambda t: t.to(device)
+    st = hip_settings(cam, bg, sh_degree, scale_modifier, device)
+    colors = e if colors_precomp is None else torch.as_tensor(colors_precomp, dtype=torch.float32).to(device)
+    cov = e if cov3D_precomp is None else torch.as_tensor(cov3D_precomp, dtype=torch.float32).to(device)
+    sh = d(g.shs) if colors_precomp is None else e
+    scales = d(g.scales) if cov3D_precomp is None else e
+    rots = d(g.rotations) if cov3D_precomp is None else e
+    means3D, opac = d(g.xyz), d(g.opacities)
+    R, color, radii, gb, bb, ib = rz.rasterize_gaussians_forward(
+        st.bg, means3D, colors, opac, scales, rots, scale_modifier, cov, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy,
+        st.image_height, st.image_width, sh, sh_degree, st.campos, False, False)
+    ex = rz.debug_export(means3D.shape[0], R, cam.image_width, cam.image_height, gb, bb, ib)
+    torch.cuda.synchronize()
+    ctx = dict(st=st, means3D=means3D, colors=colors, opac=opac, scales=scales, rots=rots, cov=cov, sh=sh, R=R, radii=radii,
+               gb=gb, bb=bb, ib=ib, color=color, ex=ex, sh_degree=sh_degree, scale_modifier=scale_modifier)
+    return ctx
+
+
+def hip_backward_raw(ctx, dL_dpix):
+    from based_on_point_cloud_partitions_amd import rasterizer as rz
+
+    st = ctx["st"]
+    dL = torch.as_tensor(dL_dpix, dtype=torch.float32).to(ctx["means3D"].device)
+    out = rz.rasterize_gaussians_backward(
+        st.bg, ctx["means3D"], ctx["radii"], ctx["colors"], ctx["scales"], ctx["rots"], ctx["scale_modifier"], ctx["cov"],
+        st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, dL, ctx["sh"], ctx["sh_degree"], st.campos, ctx["gb"], ctx["R"],
+        ctx["bb"], ctx["ib"], False)
+    torch.cuda.synchronize()
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
+    return {k: v.cpu().numpy() for k, v in zip(names, out)}
+
+
+def assert_forward_bit_exact(ctx, st, colors_precomp=None):
+    """HIP forward vs oracle state: every integer output and (thanks to the shared arithmetic contract) every float."""
+    ex = {k: v.cpu().numpy() for k, v in ctx["ex"].items()}
+    vis = st["radii"] > 0
+    assert ctx["R"] == st["num_rendered"]
+    assert np.array_equal(ctx["radii"].cpu().numpy(), st["radii"])
+    assert np.array_equal(ex["tiles_touched"].view(np.uint32), st["tiles_touched"])
+    assert np.array_equal(ex["point_offsets"].view(np.uint32), st["point_offsets"])
+    assert np.array_equal(ex["depths"].view(np.uint32)[vis], st["depths"].view(np.uint32)[vis])
+    assert np.array_equal(ex["means2D"].view(np.uint32)[vis], st["means2D"].view(np.uint32)[vis])
+    assert np.array_equal(ex["conic_opacity"].view(np.uint32)[vis], st["conic_opacity"].view(np.uint32)[vis])
+    want_rgb = st["rgb"] if colors_precomp is None else np.asarray(colors_precomp, np.float32)  # precomputed colours are carried through
+    assert np.array_equal(ex["rgb"].view(np.uint32)[vis], want_rgb.view(np.uint32)[vis])
+    assert np.array_equal(ex["keys_sorted"].view(np.uint64), st["keys_sorted"])
+    assert np.array_equal(ex["point_list"].view(np.uint32), st["point_list"])
+    assert np.array_equal(ex["ranges"].view(np.uint32), st["ranges"])
+    assert np.array_equal(ex["n_contrib"].view(np.uint32), st["n_contrib"])
+    assert np.array_equal(ex["final_T"].view(np.uint32), st["final_T"].view(np.uint32))
+    assert np.array_equal(ctx["color"].cpu().numpy().view(np.uint32), st["out_color"].view(np.uint32))
+    return ex
+
+
+GRAD_TOL = 1e-4  # BASELINE.json: "within 1e-4 abs on rendered RGB/grad"; applied relative to each tensor's scale
+
+
+def assert_grads_close(got, want, tol=GRAD_TOL):
+    """|got - want| <= tol * max(1, max|want|) element-wise, per gradient tensor."""
+    worst = {}
+    for k in got:
+        a, b = got[k].astype(np.float64).reshape(-1), want[k].astype(np.float64).reshape(-1)
+        if a.size == 0:
+            continue
+        scale = max(1.0, float(np.abs(b).max()))
+        err = float(np.abs(a - b).max())
+        worst[k] = err / scale
+        assert err <= tol * scale, f"{k}: max abs err {err:.3e} vs scale {scale:.3e}"
+    return worst

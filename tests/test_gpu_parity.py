@@ -1,0 +1,272 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star / BASELINE.md §5): bit-exact radii, tiles_touched, depth bits, sort keys,
+point_list, ranges, n_contrib -- and, because oracle and kernels share one arithmetic contract, also bit-exact
+final_T and out_color; gradients within 1e-4 (relative to each tensor's scale; the reference itself sums them with
+order-dependent float atomics).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import (assert_forward_bit_exact, assert_grads_close, hip_backward_raw, hip_forward_raw, hip_settings,
+                     oracle_forward, scene)
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _fwd_bwd(P, W, H, focal, seed=0, bg=(0.0, 0.0, 0.0), deg=3, scale_lo=0.004, scale_hi=0.04, cam_index=0, n_cams=4,
+             colors=False, cov=False, scale_modifier=1.0, backward=True):
+    g, cam = scene(P, W, H, focal, seed=seed, scale_lo=scale_lo, scale_hi=scale_hi, cam_index=cam_index, n_cams=n_cams)
+    rng = np.random.default_rng(seed + 100)
+    cp = rng.uniform(0, 1, (P, 3)).astype(np.float32) if colors else None
+    cv = None
+    if cov:
+        A = rng.normal(0, 0.05, (P, 3, 3))
+        S = A @ A.transpose(0, 2, 1) + 1e-4 * np.eye(3)
+        cv = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
+    st = oracle_forward(g, cam, bg=bg, sh_degree=deg, scale_modifier=scale_modifier, colors_precomp=cp, cov3D_precomp=cv)
+    ctx = hip_forward_raw(g, cam, bg=bg, sh_degree=deg, scale_modifier=scale_modifier, colors_precomp=cp, cov3D_precomp=cv)
+    ex = assert_forward_bit_exact(ctx, st, colors_precomp=cp)
+    vis = st["radii"] > 0
+    if cp is None:
+        assert np.array_equal(ex["clamped"][vis], st["clamped"][vis])
+    if cv is None:
+        assert np.array_equal(ex["cov3D"].view(np.uint32)[vis], st["cov3D"].view(np.uint32)[vis])
+    if backward:
+        dL = rng.standard_normal((3, H, W)).astype(np.float32)
+        want = oracle.backward(st, dL)
+        got = hip_backward_raw(ctx, dL)
+        assert_grads_close(got, want)
+    return st, ctx
+
+
+def test_snapshot_scene_against_committed_golden():
+    """HIP vs the committed fixture (tests/golden/oracle_snapshot.npz: stored inputs + oracle outputs), oracle not run."""
+    import hashlib
+
+    from helpers import snapshot_scene
+
+    fx = np.load(os.path.join(G, "oracle_snapshot.npz"))
+    g, cam, bg = snapshot_scene(fx)
+    ctx = hip_forward_raw(g, cam, bg=bg, sh_degree=3)
+    ex = {k: v.cpu().numpy() for k, v in ctx["ex"].items()}
+    h = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+    assert ctx["R"] == int(fx["num_rendered"])
+    assert np.array_equal(ctx["radii"].cpu().numpy(), fx["radii"])
+    assert np.array_equal(ex["tiles_touched"].view(np.uint32), fx["tiles_touched"])
+    vis = fx["radii"] > 0
+    assert np.array_equal(ex["depths"].view(np.uint32)[vis], fx["depth_bits"][vis])
+    assert np.array_equal(h(ex["keys_sorted"].view(np.uint64)), fx["h_keys_sorted"])
+    assert np.array_equal(h(ex["point_list"].view(np.uint32)), fx["h_point_list"])
+    assert np.array_equal(ex["ranges"].view(np.uint32), fx["ranges"])
+    assert np.array_equal(ex["n_contrib"].view(np.uint32), fx["n_contrib"])
+    assert np.array_equal(ctx["color"].cpu().numpy(), fx["out_color"])
+    assert np.array_equal(ex["final_T"], fx["final_T"])
+    dL = np.random.default_rng(9).standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+    got = hip_backward_raw(ctx, dL)
+    assert_grads_close(got, {k: fx["g_" + k] for k in got})
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_small_scene_all_sh_degrees(deg):
+    _fwd_bwd(P=3000, W=160, H=128, focal=100.0, seed=deg, bg=(0.3, 0.5, 0.7), deg=deg, scale_lo=0.01, scale_hi=0.15)
+
+
+def test_config1_10k_256(request):
+    # BASELINE.json configs[0]: 10k Gaussians, 4 cameras, 256x256
+    for ci in range(4):
+        _fwd_bwd(P=10_000, W=256, H=256, focal=160.0, seed=0, cam_index=ci, n_cams=4)
+
+
+def test_image_size_not_multiple_of_tile():
+    _fwd_bwd(P=4000, W=250, H=130, focal=120.0, seed=5, bg=(0.1, 0.0, 0.9), scale_lo=0.01, scale_hi=0.1)
+
+
+def test_saturating_scene_done_path():
+    st, _ = _fwd_bwd(P=2500, W=96, H=96, focal=60.0, seed=11, scale_lo=0.3, scale_hi=1.0, bg=(0.2, 0.2, 0.2))
+    assert (st["final_T"] < 1e-3).any() and st["n_contrib"].max() > 50
+
+
+def test_long_tile_lists_multiple_batches():
+    # > 256 entries per tile: several LDS batches in both blend kernels
+    st, _ = _fwd_bwd(P=30_000, W=128, H=128, focal=80.0, seed=12, scale_lo=0.01, scale_hi=0.08)
+    assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 600
+
+
+def test_precomputed_colors_and_covariance():
+    _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=21, colors=True, cov=True, bg=(0.5, 0.5, 0.5))
+    _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=22, colors=True, cov=False)
+    _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=23, colors=False, cov=True)
+
+
+def test_scale_modifier():
+    _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=31, scale_modifier=0.6, scale_lo=0.02, scale_hi=0.2)
+
+
+def test_mid_scene_100k_vga():
+    _fwd_bwd(P=100_000, W=640, H=480, focal=400.0, seed=3, n_cams=8, cam_index=3)
+
+
+def test_config2_500k_1080p_full_parity():
+    # BASELINE.json configs[1], the headline workload, against the oracle at full size
+    st, ctx = _fwd_bwd(P=500_000, W=1920, H=1080, focal=1200.0, seed=0, n_cams=16, cam_index=0)
+    assert st["num_rendered"] > 3_000_000
+    # size-independent properties on the device results
+    ex = ctx["ex"]
+    keys = ex["keys_sorted"].cpu().numpy().view(np.uint64)
+    assert np.all(keys[1:] >= keys[:-1])
+    r = ex["ranges"].cpu().numpy().view(np.uint32)
+    ne = r[r[:, 1] > r[:, 0]]
+    assert ne[0, 0] == 0 and ne[-1, 1] == ctx["R"] and np.all(ne[1:, 0] == ne[:-1, 1])
+    assert int(ex["tiles_touched"].cpu().numpy().view(np.uint32).astype(np.int64).sum()) == ctx["R"]
+
+
+def test_backward_is_bitwise_reproducible():
+    g, cam = scene(20_000, 256, 256, 160.0, seed=4, scale_lo=0.01, scale_hi=0.1)
+    ctx = hip_forward_raw(g, cam)
+    dL = np.random.default_rng(0).standard_normal((3, 256, 256)).astype(np.float32)
+    a = hip_backward_raw(ctx, dL)
+    b = hip_backward_raw(ctx, dL)
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
+def test_all_culled_and_empty():
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    cam = syn.make_camera(64, 64, 64.0, (6.0, 0.0, 0.0))
+    P = 300
+    g = syn.make_gaussians(P, seed=1, box_min=(7.0, -1.0, -1.0), box_max=(9.0, 1.0, 1.0))  # all behind the camera
+    st = oracle_forward(g, cam, bg=(0.1, 0.2, 0.3))
+    ctx = hip_forward_raw(g, cam, bg=(0.1, 0.2, 0.3))
+    assert ctx["R"] == 0 == st["num_rendered"]
+    assert np.array_equal(ctx["color"].cpu().numpy(), st["out_color"])
+    got = hip_backward_raw(ctx, np.ones((3, 64, 64), np.float32))
+    assert all(np.all(v == 0) for v in got.values())
+    # P == 0: nothing runs, colour stays 0 (rasterize_points.cu:68,82)
+    g0 = syn.SyntheticGaussians(*[t[:0] for t in g])
+    ctx0 = hip_forward_raw(g0, cam, bg=(0.1, 0.2, 0.3))
+    assert ctx0["R"] == 0 and torch.all(ctx0["color"] == 0) and ctx0["radii"].numel() == 0
+    got0 = hip_backward_raw(ctx0, np.ones((3, 64, 64), np.float32))
+    assert got0["dL_dsh"].shape == (0, 0, 3)  # M is only read when sh.size(0) != 0 (rasterize_points.cu:145-149)
+
+
+def test_autograd_function_end_to_end():
+    """Drives GaussianRasterizer the way gaussian_renderer/__init__.py:26-93 does."""
+    from based_on_point_cloud_partitions_amd import GaussianRasterizer
+
+    P, W, H = 5000, 200, 120
+    g, cam = scene(P, W, H, 110.0, seed=8, scale_lo=0.01, scale_hi=0.12)
+    bg = (0.05, 0.1, 0.15)
+    dev = "cuda"
+    xyz = g.xyz.to(dev).requires_grad_(True)
+    raw_scale = torch.log(g.scales).to(dev).requires_grad_(True)
+    raw_rot = (g.rotations * 1.7).to(dev).requires_grad_(True)
+    raw_op = torch.logit(g.opacities.clamp(1e-4, 1 - 1e-4)).to(dev).requires_grad_(True)
+    f_dc = g.shs[:, :1].to(dev).requires_grad_(True)
+    f_rest = g.shs[:, 1:].to(dev).requires_grad_(True)
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
+    screenspace_points.retain_grad()
+    rast = GaussianRasterizer(hip_settings(cam, bg, 3, device=dev))
+    scales, rots, opac = torch.exp(raw_scale), torch.nn.functional.normalize(raw_rot), torch.sigmoid(raw_op)
+    shs = torch.cat((f_dc, f_rest), dim=1)
+    image, radii = rast(means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opac, scales=scales,
+                        rotations=rots, cov3D_precomp=None)
+    assert not radii.requires_grad and radii.dtype == torch.int32
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3))
+    (image * dL.to(dev)).sum().backward()
+    # oracle on the activated values, chain rule through the activations in float64 on the host
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+    ga = syn.SyntheticGaussians(xyz.detach().cpu(), scales.detach().cpu(), rots.detach().cpu(), opac.detach().cpu(), shs.detach().cpu())
+    st = oracle_forward(ga, cam, bg=bg, sh_degree=3)
+    assert np.array_equal(image.detach().cpu().numpy(), st["out_color"])
+    assert np.array_equal(radii.cpu().numpy(), st["radii"])
+    want = oracle.backward(st, dL.numpy())
+    close = lambda a, b: np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+    assert close(xyz.grad.cpu().numpy(), want["dL_dmeans3D"])
+    assert close(screenspace_points.grad.cpu().numpy(), want["dL_dmeans2D"])
+    assert close(f_dc.grad.cpu().numpy(), want["dL_dsh"][:, :1]) and close(f_rest.grad.cpu().numpy(), want["dL_dsh"][:, 1:])
+    assert close(raw_scale.grad.cpu().numpy(), want["dL_dscales"] * scales.detach().cpu().numpy())
+    o = opac.detach().cpu().numpy()
+    assert close(raw_op.grad.cpu().numpy(), want["dL_dopacity"] * o * (1 - o))
+    vis = rast.markVisible(xyz.detach())
+    assert np.array_equal(vis.cpu().numpy(), oracle.mark_visible(ga.xyz.numpy(), cam.world_view_transform.numpy(),
+                                                                 cam.full_proj_transform.numpy()))
+
+
+def test_runs_on_a_non_default_stream():
+    g, cam = scene(5000, 128, 128, 90.0, seed=2, scale_lo=0.01, scale_hi=0.1)
+    st = oracle_forward(g, cam)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx = hip_forward_raw(g, cam)
+    assert_forward_bit_exact(ctx, st)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# radix sort and kNN
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,end_bit", [(1, 45), (63, 41), (4096, 45), (4097, 45), (100_003, 45), (1_000_000, 41), (50_000, 32),
+                                       (50_000, 64), (70_000, 8), (70_000, 13)])
+def test_radix_sort_is_stable_and_correct(n, end_bit):
+    import ctypes
+
+    from based_on_point_cloud_partitions_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(n + end_bit)
+    # few distinct values in the high bits + random low bits: many duplicates -> stability matters
+    keys = (rng.integers(0, 1 << 13, n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 10, n, dtype=np.uint64)
+    if end_bit < 64:
+        keys &= np.uint64((1 << end_bit) - 1)
+    else:
+        keys |= rng.integers(0, 2, n, dtype=np.uint64) << np.uint64(63)
+    vals = np.arange(n, dtype=np.uint32)
+    dev = "cuda"
+    ka = torch.from_numpy(keys.view(np.int64)).to(dev)
+    va = torch.from_numpy(vals.view(np.int32)).to(dev)
+    kb, vb = torch.empty_like(ka), torch.empty_like(va)
+    scratch = torch.empty(lib.gsr_sort_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    r = _lib.check(lib.gsr_sort_pairs(p(ka), p(kb), p(va), p(vb), n, end_bit, p(scratch), scratch.numel(),
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_sort_pairs")
+    torch.cuda.synchronize()
+    ko = (kb if r else ka).cpu().numpy().view(np.uint64)
+    vo = (vb if r else va).cpu().numpy().view(np.uint32)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ko, keys[order])
+    assert np.array_equal(vo, vals[order])
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 7, 1023, 1024, 1025, 5000, 100_000])
+def test_knn_bit_exact(P):
+    from based_on_point_cloud_partitions_amd import distCUDA2
+
+    pts = np.random.default_rng(P).uniform(-4, 4, (P, 3)).astype(np.float32)
+    if P >= 5000:
+        pts[17] = pts[4000]  # exact duplicates
+        pts[18] = pts[4000]
+    want = oracle.knn_mean_dist2(pts)
+    got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_knn_config2_points_and_fixture():
+    from based_on_point_cloud_partitions_amd import distCUDA2
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    fx = np.load(os.path.join(G, "oracle_knn.npz"))
+    got = distCUDA2(torch.from_numpy(fx["pts"]).cuda()).cpu().numpy()
+    assert np.array_equal(got, fx["dist2"])
+    pts = syn.make_gaussians(500_000, seed=0).xyz
+    want = oracle.knn_mean_dist2(pts.numpy())
+    got = distCUDA2(pts.cuda()).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the caller's post-processing (scene/gaussian_model.py:144-145) stays finite
+    assert torch.isfinite(torch.log(torch.sqrt(torch.clamp_min(torch.from_numpy(got), 1e-7)))).all()
