@@ -1,0 +1,80 @@
+"""Seamless merge of independently trained partitions: the one exchange step of the path.
+
+Semantics follow scene/ptgs/merge_partitions.py:95-170 (and scene/sever_code/merge_partitions.py:54-106):
+  1. every partition keeps the Gaussians inside its `origin_box` -- closed intervals, a side without a neighbouring
+     partition is left open (`dynamic_bounding_box`, :10-57; `extract_point_cloud_mask`, :95-109);
+  2. the survivors of all partitions are concatenated in partition order;
+  3. `np.unique(points, axis=0, return_index=True)` (:152-158): exact-xyz duplicates keep their FIRST occurrence and the
+     result is emitted in lexicographic (x, y, z) order.
+The reference does this through PLY files on disk; here every rank holds its partition's `[N_i, 59]` block of raw
+(pre-activation) parameters -- xyz 3, f_dc 3, f_rest 45, opacity 1, scale 3, rot 4, the PLY column order of
+scene/gaussian_model.py:189-220 without the normals -- and the exchange is two all-gathers (counts, then padded blocks)
+over torch.distributed: RCCL over xGMI on the 8-GPU node (backend "nccl"), gloo in the CPU tests.  ~118 MB per rank
+at 500k Gaussians, so a single un-bucketed all-gather is the right size for the point-to-point xGMI links.
+"""
+import torch
+
+ROW = 59  # floats per Gaussian in the exchange block
+
+
+def pack_block(xyz, f_dc, f_rest, opacity, scaling, rotation):
+    """[N,3],[N,1,3] or [N,3],[N,15,3] or [N,45],[N,1],[N,3],[N,4] -> [N,59] in PLY column order
+    (save_ply flattens features as transpose(1,2).flatten(1): channel-major)."""
+    N = xyz.shape[0]
+    if f_dc.dim() == 3:
+        f_dc = f_dc.transpose(1, 2).reshape(N, -1)
+    if f_rest.dim() == 3:
+        f_rest = f_rest.transpose(1, 2).reshape(N, -1)
+    return torch.cat((xyz, f_dc, f_rest, opacity.reshape(N, 1), scaling, rotation), dim=1).contiguous()
+
+
+def crop_mask(xyz, box):
+    """box = (minx, miny, maxx, maxy); None = open side (no neighbouring partition on that side)."""
+    minx, miny, maxx, maxy = box
+    mask = torch.ones(xyz.shape[0], dtype=torch.bool, device=xyz.device)
+    if minx is not None:
+        mask &= xyz[:, 0] >= minx
+    if maxx is not None:
+        mask &= xyz[:, 0] <= maxx
+    if miny is not None:
+        mask &= xyz[:, 1] >= miny
+    if maxy is not None:
+        mask &= xyz[:, 1] <= maxy
+    return mask
+
+
+def dedup_first_lexicographic(rows):
+    """np.unique(rows[:, :3], axis=0, return_index=True) semantics applied to whole rows: output sorted by (x,y,z),
+    for equal xyz the row with the smallest original index survives."""
+    n = rows.shape[0]
+    if n == 0:
+        return rows
+    order = torch.arange(n, device=rows.device)
+    for col in (2, 1, 0):  # stable sorts from the least significant key
+        _, idx = torch.sort(rows[order, col], stable=True)
+        order = order[idx]
+    s = rows[order, :3]
+    first = torch.ones(n, dtype=torch.bool, device=rows.device)
+    first[1:] = (s[1:] != s[:-1]).any(dim=1)
+    return rows[order[first]]
+
+
+def merge_partitions(block, box, group=None):
+    """Collective: every rank passes its own [N_i, 59] block and crop box and receives the merged [N, 59] scene."""
+    import torch.distributed as dist
+
+    kept = block[crop_mask(block[:, :3], box)].contiguous()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return dedup_first_lexicographic(kept)
+    world = dist.get_world_size(group)
+    count = torch.tensor([kept.shape[0]], dtype=torch.int64, device=block.device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    maxn = max(max(counts), 1)
+    padded = torch.zeros((maxn, ROW), dtype=block.dtype, device=block.device)
+    padded[:kept.shape[0]] = kept
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded, group=group)
+    allrows = torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)  # partition (= rank) order
+    return dedup_first_lexicographic(allrows)

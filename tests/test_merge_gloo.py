@@ -1,0 +1,86 @@
+"""world_size-2 gloo test of the only collective on the path: the partition merge."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from based_on_point_cloud_partitions_amd import merge
+
+
+def _blocks():
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-1, 1, (700, merge.ROW)).astype(np.float32)
+    b = rng.uniform(-1, 1, (500, merge.ROW)).astype(np.float32)
+    a[:, 0] = rng.uniform(-4, 0.5, 700)   # partition 0 covers x <= 0 plus a margin
+    b[:, 0] = rng.uniform(-0.5, 4, 500)   # partition 1 covers x >= 0 plus a margin
+    b[:40, :3] = a[100:140, :3]           # Gaussians in the overlap that both partitions carry (same xyz, other params)
+    a[5, 0] = 0.0                         # exactly on the shared boundary: kept by both (closed intervals), deduplicated
+    b[41, :3] = a[5, :3]
+    a[7, :3] = a[6, :3]                   # duplicate inside one partition
+    return a, b
+
+
+BOXES = [(None, None, 0.0, None), (0.0, None, None, None)]  # shared edge x = 0; outer sides open (no neighbour)
+
+
+def _reference(a, b):
+    """The reference's numpy sequence (scene/ptgs/merge_partitions.py:95-109,143-158)."""
+    kept = []
+    for blk, (minx, miny, maxx, maxy) in zip((a, b), BOXES):
+        m = np.ones(len(blk), bool)
+        if minx is not None:
+            m &= blk[:, 0] >= minx
+        if maxx is not None:
+            m &= blk[:, 0] <= maxx
+        kept.append(blk[m])
+    allr = np.concatenate(kept, 0)
+    pts, idx = np.unique(allr[:, :3], axis=0, return_index=True)
+    return allr[idx]
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = _blocks()
+    mine = torch.from_numpy((a, b)[rank])
+    merged = merge.merge_partitions(mine, BOXES[rank])
+    np.save(os.path.join(out_dir, f"merged_{rank}.npy"), merged.numpy())
+    dist.destroy_process_group()
+
+
+def test_merge_two_ranks_matches_numpy_unique(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = _reference(*_blocks())
+    for r in range(2):
+        got = np.load(tmp_path / f"merged_{r}.npy")
+        assert got.shape == want.shape
+        assert np.array_equal(got, want)
+
+
+def test_dedup_and_crop_single_process():
+    a, b = _blocks()
+    rows = torch.from_numpy(np.concatenate([a, b], 0))
+    got = merge.dedup_first_lexicographic(rows).numpy()
+    allr = np.concatenate([a, b], 0)
+    _, idx = np.unique(allr[:, :3], axis=0, return_index=True)
+    assert np.array_equal(got, allr[idx])
+    assert merge.dedup_first_lexicographic(rows[:0]).shape == (0, merge.ROW)
+    m = merge.crop_mask(torch.tensor([[0.0, 0.0, 0.0], [1.0, 5.0, 0.0], [-1.0, 0.0, 0.0]]), (0.0, None, 1.0, 2.0))
+    assert m.tolist() == [True, False, False]
+
+
+def test_pack_block_matches_ply_column_order():
+    N = 4
+    xyz, f_dc, f_rest = torch.rand(N, 3), torch.rand(N, 1, 3), torch.rand(N, 15, 3)
+    op, sc, rot = torch.rand(N, 1), torch.rand(N, 3), torch.rand(N, 4)
+    blk = merge.pack_block(xyz, f_dc, f_rest, op, sc, rot)
+    assert blk.shape == (N, merge.ROW)
+    # scene/gaussian_model.py:208-209: transpose(1, 2).flatten(start_dim=1)
+    assert torch.equal(blk[:, 6:51], f_rest.transpose(1, 2).flatten(start_dim=1))
+    assert torch.equal(blk[:, 51:52], op) and torch.equal(blk[:, 55:], rot)
