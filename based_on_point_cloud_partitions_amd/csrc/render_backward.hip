@@ -16,23 +16,32 @@
 
 namespace {
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v)
+// Sums 9 registers over the 64 lanes of a wave; totals are valid in lane 63.  One v_add_f32_dpp per value and level,
+// written as ONE asm block in level-major order: every DPP read is 8 instructions behind the write it depends on, so
+// no wait states are needed inside (hipcc pads nothing in asm), and the compiler cannot SLP-pack the adds into
+// v_pk_add_f32 + v_mov_dpp pairs (which is what it emits for the builtin form: 2.5x the instructions).
+// Must be executed with all 64 lanes active (it is only called under a wave-uniform condition).
+#define GSR_DPP_LEVEL(ctrl)                    \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n"      \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n"      \
+    "v_add_f32_dpp %2, %2, %2 " ctrl "\n"      \
+    "v_add_f32_dpp %3, %3, %3 " ctrl "\n"      \
+    "v_add_f32_dpp %4, %4, %4 " ctrl "\n"      \
+    "v_add_f32_dpp %5, %5, %5 " ctrl "\n"      \
+    "v_add_f32_dpp %6, %6, %6 " ctrl "\n"      \
+    "v_add_f32_dpp %7, %7, %7 " ctrl "\n"      \
+    "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
+__device__ __forceinline__ void wave_sum9_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6,
+                                                    float& v7, float& v8)
 {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-    return v + __int_as_float(t);
-}
-
-// Sum over the 64 lanes of a wave; the total is valid in lane 63.
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-    v = dpp_add<0x140, 0xF>(v);  // row_mirror   -> every lane holds its row-of-16 total
-    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3 += rows 0,2
-    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3 += lanes 0..31
-    return v;
+    asm volatile("s_nop 1\n"
+                 GSR_DPP_LEVEL("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 GSR_DPP_LEVEL("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 GSR_DPP_LEVEL("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 GSR_DPP_LEVEL("row_mirror row_mask:0xf bank_mask:0xf")
+                 GSR_DPP_LEVEL("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 GSR_DPP_LEVEL("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
 }
 
 constexpr int NV = 9;                   // partial sums per list entry
@@ -108,57 +117,47 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
         const int nb = (int)min(256u, hi - (uint32_t)i * 256);
         for (int j = 0; j < nb; j++) {
             const uint32_t kidx = hi - 1 - ((uint32_t)i * 256 + j);
-            bool contrib = false;
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-            if (kidx < last_contributor) {
-                const float4 a = s_a[j];
-                const float4 b = s_b[j];
-                const float dx = a.x - pixf_x, dy = a.y - pixf_y;
-                // identical to the forward (CONTRACT-FMA)
-                const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
-                const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
-                if (power <= 0.0f && !(power < b.z)) {
-                    const float G = gsr_expf(power);
-                    const float alpha = fminf(0.99f, b.y * G);
-                    if (alpha >= 1.0f / 255.0f) {
-                        contrib = true;
-                        const float4 c = s_c[j];
-                        const float inv = 1.0f / (1.f - alpha);
-                        T = T * inv;  // T / (1 - alpha), backward.cu:502
-                        const float dchannel_dcolor = alpha * T;
-                        const float oma = 1.f - last_alpha;
-                        accum0 = last_alpha * lc0 + oma * accum0;
-                        accum1 = last_alpha * lc1 + oma * accum1;
-                        accum2 = last_alpha * lc2 + oma * accum2;
-                        lc0 = c.x; lc1 = c.y; lc2 = c.z;
-                        float dL_dalpha = (c.x - accum0) * dL0 + (c.y - accum1) * dL1 + (c.z - accum2) * dL2;
-                        v6 = dchannel_dcolor * dL0;
-                        v7 = dchannel_dcolor * dL1;
-                        v8 = dchannel_dcolor * dL2;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final * inv) * bg_dot;
-                        const float dL_dG = b.y * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                        const float dG_ddely = -gdy * b.x - gdx * a.w;
-                        v0 = dL_dG * dG_ddelx * ddelx_dx;
-                        v1 = dL_dG * dG_ddely * ddely_dy;
-                        v2 = -0.5f * gdx * dx * dL_dG;
-                        v3 = -0.5f * gdx * dy * dL_dG;
-                        v4 = -0.5f * gdy * dy * dL_dG;
-                        v5 = G * dL_dalpha;
-                    }
-                }
-            }
-            if (__ballot(contrib) != 0ull) {  // wave-uniform
-                v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
-                v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
-                v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
-                if (lane == 63) {
-                    float* o = my_acc + j * NV;
-                    o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7; o[8] = v8;
-                }
+            const float4 a = s_a[j];
+            const float4 b = s_b[j];
+            const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+            // identical to the forward (CONTRACT-FMA)
+            const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
+            const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
+            bool contrib = kidx < last_contributor && power <= 0.0f && !(power < b.z);
+            if (__ballot(contrib) == 0ull) continue;  // wave-uniform
+            const float G = gsr_expf(power);
+            const float alpha = fminf(0.99f, b.y * G);
+            contrib = contrib && alpha >= 1.0f / 255.0f;
+            if (__ballot(contrib) == 0ull) continue;  // wave-uniform
+            // From here all 64 lanes run the same straight-line code; lanes that do not contribute are neutralised by
+            // selecting w = aT = 0 and by not committing their state.
+            const float4 c = s_c[j];
+            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+            const float Tn = T * inv;  // T / (1 - alpha), backward.cu:502
+            const float oma = 1.f - last_alpha;
+            const float ac0 = __builtin_fmaf(last_alpha, lc0, oma * accum0);
+            const float ac1 = __builtin_fmaf(last_alpha, lc1, oma * accum1);
+            const float ac2 = __builtin_fmaf(last_alpha, lc2, oma * accum2);
+            float dL_dalpha = (c.x - ac0) * dL0;
+            dL_dalpha = __builtin_fmaf(c.y - ac1, dL1, dL_dalpha);
+            dL_dalpha = __builtin_fmaf(c.z - ac2, dL2, dL_dalpha);
+            dL_dalpha *= Tn;
+            dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
+            // per-pair factors; everything else of backward.cu:520-554 is per-Gaussian and applied after the reduction:
+            //   dL_dopacity = S(w), dL_dconic = -0.5*o*S(w*dx*dx | w*dx*dy | w*dy*dy),
+            //   dL_dmean2D = o*(-cx*S(w*dx) - cy*S(w*dy))*0.5W, o*(-cz*S(w*dy) - cy*S(w*dx))*0.5H,  dL_dcolor = S(alpha*T*dL_dpixel)
+            const float w = contrib ? G * dL_dalpha : 0.f;
+            const float aT = contrib ? alpha * Tn : 0.f;
+            const float wdx = w * dx, wdy = w * dy;
+            float v0 = w, v1 = wdx, v2 = wdy, v3 = wdx * dx, v4 = wdx * dy, v5 = wdy * dy, v6 = aT * dL0, v7 = aT * dL1, v8 = aT * dL2;
+            T = contrib ? Tn : T;
+            accum0 = contrib ? ac0 : accum0; accum1 = contrib ? ac1 : accum1; accum2 = contrib ? ac2 : accum2;
+            lc0 = contrib ? c.x : lc0; lc1 = contrib ? c.y : lc1; lc2 = contrib ? c.z : lc2;
+            last_alpha = contrib ? alpha : last_alpha;
+            wave_sum9_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8);
+            if (lane == 63) {
+                float* o = my_acc + j * NV;
+                o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7; o[8] = v8;
             }
         }
         __syncthreads();
@@ -170,10 +169,17 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
                 r[t] = ((s_acc[tid * NV + t] + s_acc[ACC_STRIDE + tid * NV + t]) + s_acc[2 * ACC_STRIDE + tid * NV + t]) +
                        s_acc[3 * ACC_STRIDE + tid * NV + t];
             }
-            const uint32_t row = __float_as_uint(s_b[tid].w);
+            // per-Gaussian factors of backward.cu:538-554 applied once to the reduced moments
+            const float4 a = s_a[tid];
+            const float4 b = s_b[tid];
+            const float op = b.y, cx = a.z, cy = a.w, cz = b.x;
+            const float gmx = op * (-cx * r[1] - cy * r[2]) * ddelx_dx;
+            const float gmy = op * (-cz * r[2] - cy * r[1]) * ddely_dy;
+            const float hop = -0.5f * op;
+            const uint32_t row = __float_as_uint(b.w);
             float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
-            o[0] = make_float4(r[0], r[1], r[2], r[3]);
-            o[1] = make_float4(r[4], r[5], r[6], r[7]);
+            o[0] = make_float4(gmx, gmy, hop * r[3], hop * r[4]);
+            o[1] = make_float4(hop * r[5], r[0], r[6], r[7]);
             o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
         }
     }
