@@ -141,10 +141,10 @@ int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t sc
 // The blend's exp(): same fully specified algorithm as the oracle's gs_expf (independently written).
 __device__ __forceinline__ float gsr_expf(float x)
 {
-    if (x < -80.0f) return 0.0f;
-    x = x > 80.0f ? 80.0f : x;
-    const float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693359375f, x);
+    // branch-free form of: if (x < -80) return 0; if (x > 80) x = 80; ...
+    const float xc = __builtin_amdgcn_fmed3f(x, -80.0f, 80.0f);
+    const float n = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, xc);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);
     float p = 1.9875691500E-4f;
     p = __builtin_fmaf(p, r, 1.3981999507E-3f);
@@ -152,8 +152,9 @@ __device__ __forceinline__ float gsr_expf(float x)
     p = __builtin_fmaf(p, r, 4.1665795894E-2f);
     p = __builtin_fmaf(p, r, 1.6666665459E-1f);
     p = __builtin_fmaf(p, r, 5.0000001201E-1f);
-    float y = __builtin_fmaf(p, r * r, r) + 1.0f;
-    return __int_as_float(__float_as_int(y) + ((int)n << 23));
+    const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    const float e = __int_as_float(__float_as_int(y) + (int)n * (1 << 23));
+    return x < -80.0f ? 0.0f : e;
 }
 
 // auxiliary.h:46-56 -- tile rectangle of a splat (saturating float->int as the hardware converts)

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             uint32_t mnx, mny, mxx, mxy;
             gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
             const uint32_t row = __float_as_uint(q2.w) + (blockIdx.y - mny) * (mxx - mnx) + (blockIdx.x - mnx);
-            const float pthr = __logf(1.0f / (255.0f * q1.y)) - 1e-3f;
+            const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
             s_a[tid] = q0;
             s_b[tid] = make_float4(q1.x, q1.y, pthr, __uint_as_float(row));
             s_c[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
@@ -115,16 +115,21 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
         }
         __syncthreads();
         const int nb = (int)min(256u, hi - (uint32_t)i * 256);
+#pragma unroll 2
         for (int j = 0; j < nb; j++) {
             const uint32_t kidx = hi - 1 - ((uint32_t)i * 256 + j);
             const float4 a = s_a[j];
             const float4 b = s_b[j];
-            const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+            // entries behind this pixel's last contributor are parked far away (power -> -inf / NaN), so one range test
+            // covers `kidx < last_contributor`, `power <= 0` and the conservative alpha < 1/255 shortcut
+            const float px = kidx < last_contributor ? pixf_x : 1e30f;
+            const float dx = a.x - px, dy = a.y - pixf_y;
             // identical to the forward (CONTRACT-FMA)
             const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
             const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
-            bool contrib = kidx < last_contributor && power <= 0.0f && !(power < b.z);
-            if (__ballot(contrib) == 0ull) continue;  // wave-uniform
+            const bool maybe = __builtin_amdgcn_fmed3f(power, b.z, 0.0f) == power;
+            if (__ballot(maybe) == 0ull) continue;  // wave-uniform, the common case
+            bool contrib = maybe && kidx < last_contributor && power <= 0.0f;
             const float G = gsr_expf(power);
             const float alpha = fminf(0.99f, b.y * G);
             contrib = contrib && alpha >= 1.0f / 255.0f;

@@ -30,18 +30,22 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     const uint32_t pix_x = blockIdx.x * GSR_TILE_X + (tid & 15), pix_y = blockIdx.y * GSR_TILE_Y + (tid >> 4);
     const bool inside = pix_x < (uint32_t)W && pix_y < (uint32_t)H;
     const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
-    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    // tile range is workgroup-uniform: keep it (and every loop bound derived from it) in scalar registers
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+    const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const int total = (int)(r1 - r0);
     const int rounds = (total + 255) / 256;
 
-    bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t contributor = 0, last_contributor = 0;
-    int toDo = total;
+    uint32_t last_contributor = 0;
+    // `done` is encoded in px: a finished (or outside) pixel is parked at x = PARKED, which drives its `power` to
+    // -inf/NaN so the single range test of the hot loop rejects it -- no `done` mask, no EXEC branch per entry.
+    constexpr float PARKED = 1e30f;
+    float px = inside ? pixf_x : PARKED;
+    bool wave_done = __ballot(px != PARKED) == 0ull;
 
-    for (int i = 0; i < rounds; i++, toDo -= 256) {
-        // workgroup-wide early exit
-        const bool wave_done = __ballot(!done) == 0ull;
+    for (int i = 0; i < rounds; i++) {
+        // workgroup-wide early exit (forward.cu:301-304)
         if ((tid & 63) == 0) s_done[wave] = wave_done;
         __syncthreads();
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
@@ -50,43 +54,52 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             const uint32_t id = point_list[r0 + progress];
             const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-            // conservative skip threshold on `power` (see header); NaN (opacity <= 0) never skips
-            const float pthr = __logf(1.0f / (255.0f * q1.y)) - 1e-3f;
+            // conservative skip threshold on `power` (see header); opacity <= 0 or NaN never skips
+            const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
             s_a[tid] = q0;
             s_b[tid] = make_float4(q1.x, q1.y, pthr, 0.f);
             s_c[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
+        } else {
+            // padding entry that can never pass the range test (lets the hot loop run in groups of 4 without bounds checks)
+            s_a[tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
+            s_b[tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
         }
         __syncthreads();
         if (!wave_done) {
-            const int nb = min(256, toDo);
-            for (int j = 0; j < nb; j++) {
-                if (__ballot(!done) == 0ull) break;
-                if (!done) {
-                    contributor++;
+            const int nb = min(256, total - i * 256);
+            for (int j0 = 0; j0 < nb; j0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + u;
                     const float4 a = s_a[j];
                     const float4 b = s_b[j];
-                    const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+                    const float dx = a.x - px, dy = a.y - pixf_y;
                     // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
                     const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
                     const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
-                    if (power <= 0.0f && !(power < b.z)) {
-                        const float alpha = fminf(0.99f, b.y * gsr_expf(power));
-                        if (alpha >= 1.0f / 255.0f) {
-                            const float test_T = T * (1.0f - alpha);
-                            if (test_T < 0.0001f) {
-                                done = true;
-                            } else {
-                                const float4 c = s_c[j];
-                                // CONTRACT-FMA: C += (f*alpha)*T
-                                C0 = __builtin_fmaf(c.x * alpha, T, C0);
-                                C1 = __builtin_fmaf(c.y * alpha, T, C1);
-                                C2 = __builtin_fmaf(c.z * alpha, T, C2);
-                                T = test_T;
-                                last_contributor = contributor;
+                    // pthr <= power <= 0  <=>  med3(power, pthr, 0) == power  (superset when pthr > 0; the exact path re-tests)
+                    const bool maybe = __builtin_amdgcn_fmed3f(power, b.z, 0.0f) == power;
+                    if (__ballot(maybe) != 0ull) {  // wave-uniform; rare relative to the skip
+                        if (maybe && px != PARKED && power <= 0.0f) {
+                            const float alpha = fminf(0.99f, b.y * gsr_expf(power));
+                            if (alpha >= 1.0f / 255.0f) {
+                                const float test_T = T * (1.0f - alpha);
+                                if (test_T < 0.0001f) {
+                                    px = PARKED;  // done
+                                } else {
+                                    const float4 c = s_c[j];
+                                    // CONTRACT-FMA: C += (f*alpha)*T
+                                    C0 = __builtin_fmaf(c.x * alpha, T, C0);
+                                    C1 = __builtin_fmaf(c.y * alpha, T, C1);
+                                    C2 = __builtin_fmaf(c.z * alpha, T, C2);
+                                    T = test_T;
+                                    last_contributor = (uint32_t)(i * 256 + j + 1);  // = `contributor` of forward.cu:322
+                                }
                             }
                         }
                     }
                 }
+                if (__ballot(px != PARKED) == 0ull) { wave_done = true; break; }
             }
         }
     }
