@@ -91,14 +91,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU; the modulo only matters for 1-GPU rehearsals
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GSR_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = syn.CONFIGS[args.config]
     P, W, H = cfg["P"], cfg["W"], cfg["H"]
@@ -168,7 +173,7 @@ def main():
     _lib.profile_enable(False)
     stage = _lib.profile_collect() if use_timers else {}
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
