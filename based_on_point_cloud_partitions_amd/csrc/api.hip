@@ -1,6 +1,7 @@
 // extern "C" entry points of libgsrast_mi355x.so (declared in include/gsrast_mi355x.h).
 // Host-side orchestration only: buffer layouts, argument checks, stage launches on the caller's stream.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -71,6 +72,14 @@ __global__ void __launch_bounds__(256) export_geom_kernel(int P, const float* __
 }
 
 }  // namespace
+
+int gsr_variant(const char* name, int dflt)
+{
+    char key[64];
+    snprintf(key, sizeof(key), "GSR_%s", name);
+    const char* v = getenv(key);
+    return v ? atoi(v) : dflt;
+}
 
 extern "C" {
 
@@ -169,8 +178,10 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
     }
     {
         StageTimer t(GSR_STAGE_RENDER_FWD, s);
+        uint8_t* flags = R > 0 ? (uint8_t*)(b + B.flags) : nullptr;
+        if (flags && gsr_variant("FLAGS", 0)) hipMemsetAsync(flags, 0, (size_t)R, s);
         gsr_launch_render_forward(W, H, ranges, point_list, (const float*)(g + G.splat), background, (float*)(im + I.final_T),
-                                  (uint32_t*)(im + I.n_contrib), out_color, s);
+                                  (uint32_t*)(im + I.n_contrib), out_color, flags, s);
     }
     return check_hip("forward_render");
 }
@@ -207,7 +218,7 @@ int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* back
         StageTimer t(GSR_STAGE_RENDER_BWD, s);
         gsr_launch_render_backward(W, H, (const uint32_t*)(im + I.ranges), point_list, (const float*)(g + G.splat), background,
                                    (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
-                                   (float*)scratch, s);
+                                   (const uint8_t*)(b + B.flags), (float*)scratch, s);
     }
     GaussBackwardArgs a;
     a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;

@@ -29,7 +29,7 @@ struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
 };
 struct BinLayout {
-    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, bytes;
+    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, flags, bytes;
     uint32_t sort_blocks;
 };
 
@@ -81,6 +81,7 @@ static inline BinLayout gsr_bin_layout(long R)
     L.vals_b = o; o = gsr_align(o + r * 4);
     L.hist_global = o; o = gsr_align(o + 8 * 256 * 4);
     L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
+    L.flags = o; o = gsr_align(o + r);  // per sorted instance: bit w = wave w of the tile blended it (forward -> backward)
     L.bytes = o;
     return L;
 }
@@ -117,10 +118,12 @@ int gsr_launch_radix_sort(uint64_t* ka, uint64_t* kb, uint32_t* va, uint32_t* vb
 static inline int gsr_sort_result_in_b(int end_bit) { return (((end_bit + 7) / 8) & 1); }
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
-                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, hipStream_t s);
+                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, uint8_t* flags,
+                               hipStream_t s);
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                                float* grad_rows, hipStream_t s);
+                                const uint8_t* flags, float* grad_rows, hipStream_t s);
+int gsr_variant(const char* name, int dflt);  // experiment switch read from the environment (GSR_<name>)
 struct GaussBackwardArgs {
     int P, D, M, W, H;
     const float *means3D, *shs, *scales, *rotations, *cov3D_in /* precomp or computed */, *viewmatrix, *projmatrix, *campos;

@@ -1,4 +1,4 @@
-// Backward of the alpha compositing, one 16x16 tile per 256-thread workgroup (4 wave64s).
+// Backward of the alpha compositing, one 16x16 tile per 256-thread workgroup (4 wave64s, each a 16x4 pixel strip).
 // Replaces renderCUDA, cuda_rasterizer/backward.cu:399-557.
 //
 // The reference issues 9 global float atomicAdds per contributing (pixel, Gaussian) pair
@@ -10,8 +10,13 @@
 // the rows of one Gaussian are contiguous and the per-Gaussian kernel sums them in a fixed order:
 // gradients are bitwise reproducible run to run, unlike the reference's.
 //
+// What is reduced are MOMENTS of w = G*dL/dalpha (S w, S w*dx, S w*dy, S w*dx^2, S w*dx*dy, S w*dy^2) and
+// S alpha*T*dL/dpixel; the per-Gaussian factors of backward.cu:538-554 (opacity, conic, 0.5*W, 0.5*H) are applied
+// once per list entry after the reduction instead of once per pixel.
+//
 // Traversal is back to front from the tile's largest n_contrib (entries behind it contribute to no pixel,
 // backward.cu:480-482); alpha / G are recomputed with exactly the forward's arithmetic.
+// The kernel is VALU-issue bound; see DESIGN.md §4 for the instruction budget.
 #include "common.h"
 
 namespace {
@@ -44,9 +49,66 @@ __device__ __forceinline__ void wave_sum9_to_lane63(float& v0, float& v1, float&
                  : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
 }
 
-constexpr int NV = 9;                   // partial sums per list entry
-constexpr int ACC_STRIDE = 256 * NV;    // floats per wave
+// Reduce-scatter form of the same sum: after each exchange a lane keeps only half of the values, so 8 values cost
+// 12 + 6 + 4 + 1 instructions for the four in-row levels instead of 32; the 9th value is reduced along its row
+// (4 DPP adds) and parked in lane 8 of each row, and the two cross-row levels are shared by all nine.
+// Result: lane l < 8 holds the wave total of value (4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1)), lane 8 holds the total of v8.
+// m0/m1/m2/m8: lane masks (l&1), (l&2), (l&4), ((l&15)==8).  All 64 lanes must be active.
+__device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                                   float v8, unsigned long long m0, unsigned long long m1,
+                                                   unsigned long long m2, unsigned long long m8)
+{
+    float t0, t1, t2, t3;
+    asm volatile(
+        // level 1: partner lane^1; lanes with bit0 keep v4..v7, the others v0..v3
+        "v_cndmask_b32 %9, %4, %0, %13\n"   // t = what the partner needs from me
+        "v_cndmask_b32 %10, %5, %1, %13\n"
+        "v_cndmask_b32 %11, %6, %2, %13\n"
+        "v_cndmask_b32 %12, %7, %3, %13\n"
+        "v_cndmask_b32 %0, %0, %4, %13\n"   // v = what I keep
+        "v_cndmask_b32 %1, %1, %5, %13\n"
+        "v_cndmask_b32 %2, %2, %6, %13\n"
+        "v_cndmask_b32 %3, %3, %7, %13\n"
+        "v_add_f32_dpp %0, %9, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %10, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %11, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %3, %12, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        // 9th value, row levels interleaved as independent work between dependent DPP steps
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        // level 2: partner lane^2; lanes with bit1 keep slots 2,3
+        "v_cndmask_b32 %9, %2, %0, %14\n"
+        "v_cndmask_b32 %10, %3, %1, %14\n"
+        "v_cndmask_b32 %0, %0, %2, %14\n"
+        "v_cndmask_b32 %1, %1, %3, %14\n"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %9, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %10, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        // level 3: partner lane^4; lanes with bit2 keep slot 1
+        "v_cndmask_b32 %9, %1, %0, %15\n"
+        "v_cndmask_b32 %0, %0, %1, %15\n"
+        "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_add_f32_dpp %0, %9, %0 row_shr:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %0, %9, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+        "s_nop 1\n"
+        // level 4: partner lane^8
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        // park the 9th value's row total in lane 8 of each row
+        "v_cndmask_b32 %0, %0, %8, %16\n"
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "=&v"(t0), "=&v"(t1),
+          "=&v"(t2), "=&v"(t3)
+        : "s"(m0), "s"(m1), "s"(m2), "s"(m8));
+    // levels 5, 6: lane-wise across the four rows
+    v0 += __shfl_xor(v0, 16, 64);
+    v0 += __shfl_xor(v0, 32, 64);
+    return v0;
+}
 
+constexpr int NV = 9;  // partial sums per list entry
+
+template <int BATCH, bool RS>
 __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ ranges,
                                                               const uint32_t* __restrict__ point_list,
                                                               const float* __restrict__ splat, const float* __restrict__ bg,
@@ -54,9 +116,10 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
                                                               const uint32_t* __restrict__ n_contrib,
                                                               const float* __restrict__ dL_dpixels, float* __restrict__ grad_rows)
 {
-    __shared__ float4 s_a[256];  // mx, my, conic.x, conic.y
-    __shared__ float4 s_b[256];  // conic.z, opacity, pthr, row index (uint bits)
-    __shared__ float4 s_c[256];  // r, g, b, -
+    constexpr int ACC_STRIDE = BATCH * NV;  // floats per wave
+    __shared__ float4 s_a[BATCH];  // mx, my, conic.x, conic.y
+    __shared__ float4 s_b[BATCH];  // conic.z, opacity, pthr, row index (uint bits)
+    __shared__ float4 s_c[BATCH];  // r, g, b, -
     __shared__ __attribute__((aligned(16))) float s_acc[4 * ACC_STRIDE];
     __shared__ uint32_t s_max[4];
 
@@ -67,7 +130,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
     const size_t pix_id = (size_t)W * pix_y + pix_x;
     const size_t plane = (size_t)H * W;
     const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
-    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+    const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const uint32_t total = r1 - r0;
     if (total == 0) return;
 
@@ -86,16 +150,20 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
     if (lane == 0) s_max[wave] = m;
     __syncthreads();
-    const uint32_t hi = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
 
     float accum0 = 0.f, accum1 = 0.f, accum2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     float* my_acc = s_acc + wave * ACC_STRIDE;
-    const int rounds = (int)((hi + 255) / 256);
+    const int rounds = (int)((hi + BATCH - 1) / BATCH);
+    // reduce-scatter constants: lane masks and the accumulator slot this lane writes
+    const unsigned long long M0 = 0xAAAAAAAAAAAAAAAAull, M1 = 0xCCCCCCCCCCCCCCCCull, M2 = 0xF0F0F0F0F0F0F0F0ull,
+                             M8 = 0x0100010001000100ull;
+    const int my_slot = lane < 8 ? (4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1)) : 8;
 
     for (int i = 0; i < rounds; i++) {
         __syncthreads();  // previous batch fully flushed
-        const uint32_t progress = (uint32_t)i * 256 + tid;
-        if (progress < hi) {
+        const uint32_t progress = (uint32_t)i * BATCH + tid;
+        if (tid < BATCH && progress < hi) {
             const uint32_t k = hi - 1 - progress;
             const uint32_t id = point_list[r0 + k];
             const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
@@ -108,16 +176,17 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             s_b[tid] = make_float4(q1.x, q1.y, pthr, __uint_as_float(row));
             s_c[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
         }
-        {   // zero this wave's accumulators (9 x float4 per lane)
+        {   // zero this wave's accumulators
             float4* z = reinterpret_cast<float4*>(my_acc);
 #pragma unroll
-            for (int t = 0; t < ACC_STRIDE / 4 / 64; t++) z[t * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < (ACC_STRIDE / 4 + 63) / 64; t++)
+                if (t * 64 + lane < ACC_STRIDE / 4) z[t * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        const int nb = (int)min(256u, hi - (uint32_t)i * 256);
+        const int nb = (int)min((uint32_t)BATCH, hi - (uint32_t)i * BATCH);
 #pragma unroll 2
         for (int j = 0; j < nb; j++) {
-            const uint32_t kidx = hi - 1 - ((uint32_t)i * 256 + j);
+            const uint32_t kidx = hi - 1 - ((uint32_t)i * BATCH + j);
             const float4 a = s_a[j];
             const float4 b = s_b[j];
             // entries behind this pixel's last contributor are parked far away (power -> -inf / NaN), so one range test
@@ -128,7 +197,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
             const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
             const bool maybe = __builtin_amdgcn_fmed3f(power, b.z, 0.0f) == power;
-            if (__ballot(maybe) == 0ull) continue;  // wave-uniform, the common case
+            if (__ballot(maybe) == 0ull) continue;  // wave-uniform
             bool contrib = maybe && kidx < last_contributor && power <= 0.0f;
             const float G = gsr_expf(power);
             const float alpha = fminf(0.99f, b.y * G);
@@ -148,9 +217,6 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             dL_dalpha = __builtin_fmaf(c.z - ac2, dL2, dL_dalpha);
             dL_dalpha *= Tn;
             dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
-            // per-pair factors; everything else of backward.cu:520-554 is per-Gaussian and applied after the reduction:
-            //   dL_dopacity = S(w), dL_dconic = -0.5*o*S(w*dx*dx | w*dx*dy | w*dy*dy),
-            //   dL_dmean2D = o*(-cx*S(w*dx) - cy*S(w*dy))*0.5W, o*(-cz*S(w*dy) - cy*S(w*dx))*0.5H,  dL_dcolor = S(alpha*T*dL_dpixel)
             const float w = contrib ? G * dL_dalpha : 0.f;
             const float aT = contrib ? alpha * Tn : 0.f;
             const float wdx = w * dx, wdy = w * dy;
@@ -159,10 +225,15 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             accum0 = contrib ? ac0 : accum0; accum1 = contrib ? ac1 : accum1; accum2 = contrib ? ac2 : accum2;
             lc0 = contrib ? c.x : lc0; lc1 = contrib ? c.y : lc1; lc2 = contrib ? c.z : lc2;
             last_alpha = contrib ? alpha : last_alpha;
-            wave_sum9_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8);
-            if (lane == 63) {
-                float* o = my_acc + j * NV;
-                o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7; o[8] = v8;
+            if constexpr (RS) {
+                const float tot = wave_sum9_scatter(v0, v1, v2, v3, v4, v5, v6, v7, v8, M0, M1, M2, M8);
+                if (lane < 9) my_acc[j * NV + my_slot] = tot;
+            } else {
+                wave_sum9_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8);
+                if (lane == 63) {
+                    float* o = my_acc + j * NV;
+                    o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7; o[8] = v8;
+                }
             }
         }
         __syncthreads();
@@ -206,9 +277,16 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
 
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                                float* grad_rows, hipStream_t s)
+                                const uint8_t* flags, float* grad_rows, hipStream_t s)
 {
+    (void)flags;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(gx, gy), dim3(256), 0, s, W, H, gx, gy, ranges, point_list, splat, bg, final_T,
-                       n_contrib, dL_dpix, grad_rows);
+    const int batch = gsr_variant("BWD_BATCH", 128), rs = gsr_variant("BWD_RS", 1);
+#define GSR_BWD_LAUNCH(B, R_)                                                                                                   \
+    hipLaunchKernelGGL((render_backward_kernel<B, R_>), dim3(gx, gy), dim3(256), 0, s, W, H, gx, gy, ranges, point_list, splat, \
+                       bg, final_T, n_contrib, dL_dpix, grad_rows)
+    if (batch == 256) { if (rs) GSR_BWD_LAUNCH(256, true); else GSR_BWD_LAUNCH(256, false); }
+    else if (batch == 64) { if (rs) GSR_BWD_LAUNCH(64, true); else GSR_BWD_LAUNCH(64, false); }
+    else { if (rs) GSR_BWD_LAUNCH(128, true); else GSR_BWD_LAUNCH(128, false); }
+#undef GSR_BWD_LAUNCH
 }

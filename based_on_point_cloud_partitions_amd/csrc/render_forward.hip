@@ -117,8 +117,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
 }  // namespace
 
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
-                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, hipStream_t s)
+                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, uint8_t* flags,
+                               hipStream_t s)
 {
+    (void)flags;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     hipLaunchKernelGGL(render_forward_kernel, dim3(gx, gy), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg, final_T,
                        n_contrib, out_color);
