@@ -25,7 +25,7 @@ PROTOTYPES = {
     "gsr_last_error": (ctypes.c_char_p, []),
     "gsr_geometry_bytes": (c_size, [c_int]),
     "gsr_image_bytes": (c_size, [c_int, c_int]),
-    "gsr_binning_bytes": (c_size, [c_i64]),
+    "gsr_binning_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "gsr_backward_scratch_bytes": (c_size, [c_i64]),
     "gsr_forward_geometry": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,

@@ -88,7 +88,7 @@ const char* gsr_last_error(void) { return g_err; }
 
 size_t gsr_geometry_bytes(int P) { return gsr_geom_layout(P).bytes; }
 size_t gsr_image_bytes(int W, int H) { return gsr_image_layout(W, H).bytes; }
-size_t gsr_binning_bytes(int64_t R) { return gsr_bin_layout((long)R).bytes; }
+size_t gsr_binning_bytes(int64_t R, int P, int W, int H) { return gsr_bin_layout((long)R, P, W, H).bytes; }
 size_t gsr_backward_scratch_bytes(int64_t R) { return gsr_align((size_t)(R > 0 ? R : 1) * GSR_GROW_F * 4); }
 
 int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
@@ -142,7 +142,7 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
     if (R < 0 || R > 0xFFFFFFFFll) return fail(-1, "num_rendered out of range");
     const GeomLayout G = gsr_geom_layout(P);
     const ImageLayout I = gsr_image_layout(W, H);
-    const BinLayout B = gsr_bin_layout((long)R);
+    const BinLayout B = gsr_bin_layout((long)R, P, W, H);
     if (geom_bytes < G.bytes) return fail(-3, "geometry buffer too small");
     if (image_bytes < I.bytes) return fail(-3, "image buffer too small");
     if (R > 0 && (!binning_buffer || binning_bytes < B.bytes)) return fail(-3, "binning buffer too small");
@@ -157,6 +157,17 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
         uint64_t* kb = (uint64_t*)(b + B.keys_b);
         uint32_t* va = (uint32_t*)(b + B.vals_a);
         uint32_t* vb = (uint32_t*)(b + B.vals_b);
+        if (gsr_variant("BIN", 1)) {
+            {   // per-Gaussian instance offsets only (needed by the backward's gradient-row addressing)
+                StageTimer t(GSR_STAGE_EMIT, s);
+                gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
+                                (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets), nullptr, nullptr, s);
+            }
+            StageTimer t(GSR_STAGE_SORT, s);
+            gsr_launch_tile_binning(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
+                                    (uint32_t*)(b + B.starts), ranges, ka, va, kb, s);
+            point_list = va;
+        } else {
         {
             StageTimer t(GSR_STAGE_EMIT, s);
             gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
@@ -171,6 +182,7 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
         }
         { StageTimer t(GSR_STAGE_RANGES, s); gsr_launch_tile_ranges((uint32_t)R, in_b ? kb : ka, ranges, (uint32_t)(gx * gy), s); }
         point_list = in_b ? vb : va;
+        }
     } else {
         // point_offsets must still be valid for the backward pass; no instances -> all ranges empty
         hipMemsetAsync(g + G.point_offsets, 0, (size_t)P * 4, s);
@@ -204,7 +216,7 @@ int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* back
     if (M > 0 && !dL_dsh) return fail(-1, "dL_dsh is NULL");
     const GeomLayout G = gsr_geom_layout(P);
     const ImageLayout I = gsr_image_layout(W, H);
-    const BinLayout B = gsr_bin_layout((long)R);
+    const BinLayout B = gsr_bin_layout((long)R, P, W, H);
     if (geom_bytes < G.bytes || image_bytes < I.bytes) return fail(-3, "state buffer too small");
     if (R > 0 && (!binning_buffer || binning_bytes < B.bytes)) return fail(-3, "binning buffer too small");
     if (R > 0 && (!scratch || scratch_bytes < gsr_backward_scratch_bytes(R))) return fail(-3, "backward scratch too small");
@@ -214,7 +226,8 @@ int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* back
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     if (R > 0) {
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));
-        const uint32_t* point_list = (const uint32_t*)(b + (gsr_sort_result_in_b(end_bit) ? B.vals_b : B.vals_a));
+        const bool in_b = !gsr_variant("BIN", 1) && gsr_sort_result_in_b(end_bit);
+        const uint32_t* point_list = (const uint32_t*)(b + (in_b ? B.vals_b : B.vals_a));
         StageTimer t(GSR_STAGE_RENDER_BWD, s);
         gsr_launch_render_backward(W, H, (const uint32_t*)(im + I.ranges), point_list, (const float*)(g + G.splat), background,
                                    (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
@@ -265,7 +278,7 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
     if (P == 0) return 0;
     const GeomLayout G = gsr_geom_layout(P);
     const ImageLayout I = gsr_image_layout(W, H);
-    const BinLayout B = gsr_bin_layout((long)R);
+    const BinLayout B = gsr_bin_layout((long)R, P, W, H);
     const char* g = (const char*)geom_buffer;
     const char* b = (const char*)binning_buffer;
     const char* im = (const char*)image_buffer;
@@ -281,8 +294,9 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
     }
     if (b && R > 0) {
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));
-        const int in_b = gsr_sort_result_in_b(end_bit);
-        if (keys_sorted) hipMemcpyAsync(keys_sorted, b + (in_b ? B.keys_b : B.keys_a), (size_t)R * 8, hipMemcpyDeviceToDevice, s);
+        const int bin = gsr_variant("BIN", 1);
+        const int in_b = bin ? 0 : gsr_sort_result_in_b(end_bit);
+        if (keys_sorted) hipMemcpyAsync(keys_sorted, b + ((in_b || bin) ? B.keys_b : B.keys_a), (size_t)R * 8, hipMemcpyDeviceToDevice, s);
         if (point_list) hipMemcpyAsync(point_list, b + (in_b ? B.vals_b : B.vals_a), (size_t)R * 4, hipMemcpyDeviceToDevice, s);
     }
     if (im) {
@@ -317,7 +331,7 @@ int gsr_profile_collect(double* ms_per_stage, int64_t* launches_per_stage, int n
 
 size_t gsr_sort_scratch_bytes(int64_t n)
 {
-    const BinLayout B = gsr_bin_layout((long)n);
+    const BinLayout B = gsr_bin_layout((long)n, 1, 16, 16);
     return gsr_align(8 * 256 * 4) + gsr_align((size_t)B.sort_blocks * 256 * 4);
 }
 
@@ -328,7 +342,7 @@ int gsr_sort_pairs(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_
     if (n == 0) return ((end_bit + 7) / 8) & 1;
     if (!keys_a || !keys_b || !vals_a || !vals_b || !scratch) return fail(-1, "NULL required pointer");
     if (scratch_bytes < gsr_sort_scratch_bytes(n)) return fail(-3, "sort scratch too small");
-    const BinLayout B = gsr_bin_layout((long)n);
+    const BinLayout B = gsr_bin_layout((long)n, 1, 16, 16);
     uint32_t* hg = (uint32_t*)scratch;
     uint32_t* hb = (uint32_t*)((char*)scratch + gsr_align(8 * 256 * 4));
     const int r = gsr_launch_radix_sort(keys_a, keys_b, vals_a, vals_b, (uint32_t)n, end_bit, hg, hb, B.sort_blocks, (hipStream_t)stream);

@@ -1,0 +1,254 @@
+// Tile binning for MI355X: produces, for every 16x16 tile, the list of Gaussian ids that touch it sorted by
+// (depth bits, Gaussian id) -- bit-identical to what the reference obtains with one global stable radix sort of
+// 64-bit (tile | depth) keys over all R instances (duplicateWithKeys + cub::DeviceRadixSort::SortPairs +
+// identifyTileRanges, cuda_rasterizer/rasterizer_impl.cu:70-138,287-318).
+//
+// A 45-bit LSD sort streams 24 B/instance six times through HBM.  Here the tile id never enters a sort:
+//   1. tile_count:   each workgroup takes a slice of the Gaussians and histograms the tiles of their rectangles in LDS
+//                    (one LDS atomic per instance), then stores its row of the [workgroup][tile] table;
+//   2. tile_colscan: per tile, exclusive prefix over the workgroups (in place) + the tile's total;
+//   3. tile_starts:  exclusive scan of the totals -> tile ranges (the reference's `ranges`, empty tiles stay (0,0));
+//   4. tile_scatter: same slicing as (1); an LDS cursor per tile hands out slots, (depth bits, id) pairs go straight
+//                    into their tile's segment (8 B/instance, written once);
+//   5. tile_sort:    one workgroup per tile sorts its segment by (depth, id) in LDS with a normalized bitonic network
+//                    (all comparators ascending, so the tail is padded virtually) and writes point_list (+ keys).
+// The order in which (4) fills a segment is arbitrary (LDS atomics), but ids are unique within a tile, so the sorted
+// result is unique: ascending depth bits, ties by ascending id = the stable sort's emission order.
+// Integer/byte work, HBM + LDS bound; no MFMA.
+#include "common.h"
+
+namespace {
+
+constexpr int TCHUNK = 16384;       // tiles histogrammed per pass (64 KB of LDS counters)
+constexpr int SORT_CAP = 4096;      // list entries sorted in LDS (32 KB); longer lists are sorted in place in HBM
+
+struct SliceRect {
+    uint32_t mnx, mny, mxx, mxy, dbits;
+    bool visible;
+};
+
+__device__ __forceinline__ SliceRect load_rect(const float* __restrict__ splat, int idx, int gx, int gy)
+{
+    SliceRect r;
+    const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)idx * GSR_SPLAT_F);
+    const float4 q0 = rec[0], q2 = rec[2];
+    const int radius = __float_as_int(q2.z);
+    r.visible = radius > 0;
+    r.dbits = __float_as_uint(q2.y);
+    gsr_get_rect(q0.x, q0.y, radius, gx, gy, r.mnx, r.mny, r.mxx, r.mxy);
+    return r;
+}
+
+// (1) per-slice tile histogram.  grid = nslices, block = 256, dynamic LDS = min(T, TCHUNK) * 4 bytes.
+__global__ void __launch_bounds__(256) tile_count_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
+                                                         uint32_t* __restrict__ table)
+{
+    extern __shared__ uint32_t s_hist[];
+    const int first = blockIdx.x * gpb, last = min(P, first + gpb);
+    for (int tbase = 0; tbase < T; tbase += TCHUNK) {
+        const int tn = min(TCHUNK, T - tbase);
+        for (int t = threadIdx.x; t < tn; t += 256) s_hist[t] = 0;
+        __syncthreads();
+        for (int idx = first + threadIdx.x; idx < last; idx += 256) {
+            const SliceRect r = load_rect(splat, idx, gx, gy);
+            if (!r.visible) continue;
+            for (uint32_t y = r.mny; y < r.mxy; y++)
+                for (uint32_t x = r.mnx; x < r.mxx; x++) {
+                    const int t = (int)(y * (uint32_t)gx + x) - tbase;
+                    if (t >= 0 && t < tn) atomicAdd(&s_hist[t], 1u);
+                }
+        }
+        __syncthreads();
+        uint32_t* row = table + (size_t)blockIdx.x * T + tbase;
+        for (int t = threadIdx.x; t < tn; t += 256) row[t] = s_hist[t];
+        __syncthreads();
+    }
+}
+
+// (2) per tile: exclusive prefix over the slices (in place) and the tile total.  A workgroup owns 32 adjacent tiles
+// (128-byte rows of the table) and splits the slices into 8 groups, so the walk over the slices is 8x shorter than one
+// thread per tile and the grid (T/32 workgroups) still fills the chip.
+__global__ void __launch_bounds__(256) tile_colscan_kernel(int T, int nslices, uint32_t* __restrict__ table, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t part[8][32];
+    const int tl = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tl;
+    const int per = (nslices + 7) / 8;
+    const int b0 = sg * per, b1 = min(nslices, b0 + per);
+    uint32_t sum = 0;
+    if (t < T) {
+#pragma unroll 8
+        for (int b = b0; b < b1; b++) sum += table[(size_t)b * T + t];
+    }
+    part[sg][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int g = 0; g < sg; g++) run += part[g][tl];
+    if (t < T) {
+#pragma unroll 8
+        for (int b = b0; b < b1; b++) {
+            const size_t i = (size_t)b * T + t;
+            const uint32_t c = table[i];
+            table[i] = run;
+            run += c;
+        }
+        if (sg == 7) totals[t] = run;  // the last group ends on the tile total (empty groups pass `run` through)
+    }
+}
+
+// (3) exclusive scan of the tile totals (single workgroup) -> starts[] and the reference's ranges[] (uint2 per tile).
+__global__ void __launch_bounds__(1024) tile_starts_kernel(int T, const uint32_t* __restrict__ totals, uint32_t* __restrict__ starts,
+                                                           uint32_t* __restrict__ ranges)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < T; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < T ? totals[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += u;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < wave; w++) wbase += wtot[w];
+        const uint32_t carry = carry_s;
+        if (i < T) {
+            const uint32_t s = carry + wbase + incl - v;
+            starts[i] = s;
+            ranges[2 * i] = v ? s : 0u;          // identifyTileRanges leaves empty tiles at (0,0) after the memset
+            ranges[2 * i + 1] = v ? s + v : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
+        __syncthreads();
+    }
+}
+
+// (4) scatter (depth bits, id) into the tile segments.  Same slicing and LDS size as (1).
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
+                                                           const uint32_t* __restrict__ table, const uint32_t* __restrict__ starts,
+                                                           uint2* __restrict__ bins)
+{
+    extern __shared__ uint32_t s_cur[];
+    const int first = blockIdx.x * gpb, last = min(P, first + gpb);
+    for (int tbase = 0; tbase < T; tbase += TCHUNK) {
+        const int tn = min(TCHUNK, T - tbase);
+        const uint32_t* row = table + (size_t)blockIdx.x * T + tbase;
+        for (int t = threadIdx.x; t < tn; t += 256) s_cur[t] = row[t] + starts[tbase + t];
+        __syncthreads();
+        for (int idx = first + threadIdx.x; idx < last; idx += 256) {
+            const SliceRect r = load_rect(splat, idx, gx, gy);
+            if (!r.visible) continue;
+            for (uint32_t y = r.mny; y < r.mxy; y++)
+                for (uint32_t x = r.mnx; x < r.mxx; x++) {
+                    const int t = (int)(y * (uint32_t)gx + x) - tbase;
+                    if (t >= 0 && t < tn) {
+                        const uint32_t slot = atomicAdd(&s_cur[t], 1u);
+                        bins[slot] = make_uint2((uint32_t)idx, r.dbits);  // little-endian u64 = depth << 32 | id
+                    }
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// Normalized bitonic network on n keys held in `a` (LDS or HBM), virtually padded with +inf up to N = pow2 >= n.
+// Every comparator is ascending (lo < hi), so a comparator whose upper index is >= n is a no-op.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort_block(Ptr a, uint32_t n, uint32_t N)
+{
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t i = threadIdx.x; i < (N >> 1); i += 256) {  // mirror step
+            const uint32_t blk = i / hk, off = i - blk * hk;
+            const uint32_t lo = blk * k + off, hi = blk * k + k - 1 - off;
+            if (hi < n) {
+                const unsigned long long x = a[lo], y = a[hi];
+                if (x > y) { a[lo] = y; a[hi] = x; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < (N >> 1); i += 256) {
+                const uint32_t lo = (i / j) * 2 * j + (i % j), hi = lo + j;
+                if (hi < n) {
+                    const unsigned long long x = a[lo], y = a[hi];
+                    if (x > y) { a[lo] = y; a[hi] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// (5) one workgroup per tile.
+__global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ bins,
+                                                        uint32_t* __restrict__ point_list, unsigned long long* __restrict__ keys_sorted)
+{
+    __shared__ unsigned long long s_keys[SORT_CAP];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+    const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
+    const uint32_t n = r1 - r0;
+    if (n == 0) return;
+    uint32_t N = 1;
+    while (N < n) N <<= 1;
+    unsigned long long* seg = bins + r0;
+    if (n <= SORT_CAP) {
+        for (uint32_t i = threadIdx.x; i < n; i += 256) s_keys[i] = seg[i];
+        __syncthreads();
+        if (n > 1) bitonic_sort_block(s_keys, n, N);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const unsigned long long k = s_keys[i];
+            point_list[r0 + i] = (uint32_t)k;
+            if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
+        }
+    } else {
+        // rare: list longer than the LDS budget -> same network in place in HBM (workgroup-scope visibility via __syncthreads)
+        bitonic_sort_block(seg, n, N);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const unsigned long long k = seg[i];
+            point_list[r0 + i] = (uint32_t)k;
+            if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
+        }
+    }
+}
+
+}  // namespace
+
+int gsr_tile_slices(int P, int* gpb_out)
+{
+    int ns = (P + 1023) / 1024;
+    if (ns > 512) ns = 512;
+    if (ns < 1) ns = 1;
+    int gpb = ((P + ns - 1) / ns + 255) / 256 * 256;
+    if (gpb < 256) gpb = 256;
+    ns = (P + gpb - 1) / gpb;
+    if (ns < 1) ns = 1;
+    *gpb_out = gpb;
+    return ns;
+}
+
+void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* starts,
+                             uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted, hipStream_t s)
+{
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    const int T = gx * gy;
+    int gpb;
+    const int ns = gsr_tile_slices(P, &gpb);
+    const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
+    hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(256), lds, s, P, gpb, gx, gy, T, splat, table);
+    hipLaunchKernelGGL(tile_colscan_kernel, dim3((T + 31) / 32), dim3(256), 0, s, T, ns, table, totals);
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(1024), 0, s, T, totals, starts, ranges);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(256), lds, s, P, gpb, gx, gy, T, splat, table, starts,
+                       reinterpret_cast<uint2*>(bins));
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<unsigned long long*>(bins), point_list,
+                       reinterpret_cast<unsigned long long*>(keys_sorted));
+}

@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256) emit_keys_kernel(int P, int gx, int gy, f
     rec[SP_OFFS] = __uint_as_float(off);
     uint32_t mnx, mny, mxx, mxy;
     gsr_get_rect(mx, my, radius, gx, gy, mnx, mny, mxx, mxy);
+    if (keys == nullptr) return;  // offsets only: the tile-binning path (binning.hip) builds the lists itself
     for (uint32_t y = mny; y < mxy; y++)
         for (uint32_t x = mnx; x < mxx; x++) {
             keys[off] = ((uint64_t)(y * (uint32_t)gx + x) << 32) | dbits;

@@ -82,7 +82,7 @@ def rasterize_gaussians_forward(background, means3D, colors, opacity, scales, ro
                 _ptr(sh_c), _ptr(cov_c), _ptr(colors_c), _ptr(vm), _ptr(pm), _ptr(cp), W, H, float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), ctypes.byref(R), s), "gsr_forward_geometry")
             rendered = int(R.value)
-            binningBuffer = torch.empty(lib.gsr_binning_bytes(rendered) if rendered > 0 else 0, **byte)
+            binningBuffer = torch.empty(lib.gsr_binning_bytes(rendered, P, W, H) if rendered > 0 else 0, **byte)
             _lib.check(lib.gsr_forward_render(
                 P, rendered, W, H, _ptr(bg), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer), binningBuffer.numel(),
                 _ptr(imgBuffer), imgBuffer.numel(), _ptr(out_color), s), "gsr_forward_render")

@@ -39,7 +39,7 @@ const char* gsr_last_error(void);
  * rasterizer_impl.h:67-73) and of the backward scratch (one 48-byte gradient row per instance). */
 size_t gsr_geometry_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
-size_t gsr_binning_bytes(int64_t R);
+size_t gsr_binning_bytes(int64_t R, int P, int W, int H);
 size_t gsr_backward_scratch_bytes(int64_t R);
 
 /* Phase 1 of CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:198-285): frustum cull, covariance
@@ -51,7 +51,8 @@ int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float*
                          int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* geom_buffer,
                          size_t geom_bytes, int64_t* num_rendered_host, void* stream);
 
-/* Phase 2 (rasterizer_impl.cu:287-336): key emission, 64-bit radix sort, tile ranges, alpha compositing. */
+/* Phase 2 (rasterizer_impl.cu:287-336): tile binning (per-tile lists sorted by depth, bit-identical to the reference's
+ * key emission + 64-bit radix sort + tile ranges) and alpha compositing. */
 int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, void* geom_buffer, size_t geom_bytes,
                        void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes,
                        float* out_color, void* stream);
