@@ -161,31 +161,48 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int gpb, int g
 
 // Normalized bitonic network on n keys held in `a` (LDS or HBM), virtually padded with +inf up to N = pow2 >= n.
 // Every comparator is ascending (lo < hi), so a comparator whose upper index is >= n is a no-op.
-template <typename Ptr>
+// Comparator i of a stage is handled by wave (i / (N/2 / waves)): each of the `waves` active waves owns one contiguous
+// segment of S = N / waves positions, so every stage whose comparators stay inside a segment (stride 2j <= S, mirror
+// block k <= S) needs no workgroup barrier -- a wave's LDS operations execute in order.  Only the top log2(waves)
+// merge levels cross segments: 3 barrier stages for any N instead of log2(N)*(log2(N)+1)/2.
+template <bool LOCAL_OK, typename Ptr>
 __device__ __forceinline__ void bitonic_sort_block(Ptr a, uint32_t n, uint32_t N)
 {
-    for (uint32_t k = 2; k <= N; k <<= 1) {
+    const uint32_t half = N >> 1;
+    const uint32_t waves = half >= 256 ? 4u : (half >= 64 ? half / 64 : 1u);   // active waves
+    const uint32_t per_wave = half / waves;                                     // comparators per wave and stage
+    const uint32_t S = N / waves;                                               // positions per wave segment
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool active = wave < waves;
+    for (uint32_t k = 2, lk = 1; k <= N; k <<= 1, lk++) {  // k = 1 << lk (strides are powers of two: shifts, no division)
         const uint32_t hk = k >> 1;
-        for (uint32_t i = threadIdx.x; i < (N >> 1); i += 256) {  // mirror step
-            const uint32_t blk = i / hk, off = i - blk * hk;
-            const uint32_t lo = blk * k + off, hi = blk * k + k - 1 - off;
-            if (hi < n) {
-                const unsigned long long x = a[lo], y = a[hi];
-                if (x > y) { a[lo] = y; a[hi] = x; }
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < (N >> 1); i += 256) {
-                const uint32_t lo = (i / j) * 2 * j + (i % j), hi = lo + j;
+        if (active)
+            for (uint32_t c = lane; c < per_wave; c += 64) {  // mirror step
+                const uint32_t i = wave * per_wave + c;
+                const uint32_t blk = i >> (lk - 1), off = i & (hk - 1);
+                const uint32_t lo = (blk << lk) + off, hi = (blk << lk) + k - 1 - off;
                 if (hi < n) {
                     const unsigned long long x = a[lo], y = a[hi];
                     if (x > y) { a[lo] = y; a[hi] = x; }
                 }
             }
-            __syncthreads();
+        if (LOCAL_OK && k <= S) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+        for (uint32_t j = k >> 2, lj = lk - 2; j >= 1; j >>= 1, lj--) {  // j = 1 << lj
+            if (active)
+                for (uint32_t c = lane; c < per_wave; c += 64) {
+                    const uint32_t i = wave * per_wave + c;
+                    const uint32_t lo = ((i >> lj) << (lj + 1)) + (i & (j - 1)), hi = lo + j;
+                    if (hi < n) {
+                        const unsigned long long x = a[lo], y = a[hi];
+                        if (x > y) { a[lo] = y; a[hi] = x; }
+                    }
+                }
+            // the NEXT stage (stride j/2, or the next merge's mirror) decides which sync is needed before it
+            const uint32_t next_span = j > 1 ? j : (k << 1);  // 2*(j/2) = j, or the next mirror block size
+            if (LOCAL_OK && next_span <= S && 2 * j <= S) __builtin_amdgcn_wave_barrier(); else __syncthreads();
         }
     }
+    __syncthreads();
 }
 
 // (5) one workgroup per tile.
@@ -204,7 +221,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
     if (n <= SORT_CAP) {
         for (uint32_t i = threadIdx.x; i < n; i += 256) s_keys[i] = seg[i];
         __syncthreads();
-        if (n > 1) bitonic_sort_block(s_keys, n, N);
+        if (n > 1) bitonic_sort_block<true>(s_keys, n, N);
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const unsigned long long k = s_keys[i];
             point_list[r0 + i] = (uint32_t)k;
@@ -212,7 +229,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
         }
     } else {
         // rare: list longer than the LDS budget -> same network in place in HBM (workgroup-scope visibility via __syncthreads)
-        bitonic_sort_block(seg, n, N);
+        bitonic_sort_block<false>(seg, n, N);
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const unsigned long long k = seg[i];
             point_list[r0 + i] = (uint32_t)k;

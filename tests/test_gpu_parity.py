@@ -99,6 +99,17 @@ def test_long_tile_lists_multiple_batches():
     assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 600
 
 
+def test_very_long_tile_lists_use_the_in_place_sort_path():
+    # > 4096 entries per tile: the per-tile sort leaves LDS and runs in place in HBM (binning.hip); lists of 1k..4k
+    # entries exercise the larger LDS networks
+    st, _ = _fwd_bwd(P=120_000, W=64, H=64, focal=40.0, seed=13, scale_lo=0.004, scale_hi=0.02)
+    ln = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert ln.max() > 4096
+    st, _ = _fwd_bwd(P=60_000, W=96, H=96, focal=60.0, seed=14, scale_lo=0.004, scale_hi=0.03)
+    ln = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert ((ln > 1024) & (ln <= 4096)).any()
+
+
 def test_precomputed_colors_and_covariance():
     _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=21, colors=True, cov=True, bg=(0.5, 0.5, 0.5))
     _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=22, colors=True, cov=False)
