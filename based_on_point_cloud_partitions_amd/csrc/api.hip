@@ -240,6 +240,7 @@ int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* back
     a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
     a.radii = radii; a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);
     a.tiles_touched = (const uint32_t*)(g + G.tiles_touched);
+    a.point_offsets = (const uint32_t*)(g + G.point_offsets);
     a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
     a.has_shs = shs != nullptr; a.has_scales = scales != nullptr;
     a.grad_rows = (const float*)scratch;

@@ -140,7 +140,7 @@ int gsr_variant(const char* name, int dflt);  // experiment switch read from the
 struct GaussBackwardArgs {
     int P, D, M, W, H;
     const float *means3D, *shs, *scales, *rotations, *cov3D_in /* precomp or computed */, *viewmatrix, *projmatrix, *campos;
-    const int* radii; const uint8_t* clamped; const float* splat; const uint32_t* tiles_touched;
+    const int* radii; const uint8_t* clamped; const float* splat; const uint32_t* tiles_touched; const uint32_t* point_offsets;
     float scale_modifier, tan_fovx, tan_fovy;
     int has_shs, has_scales;
     const float* grad_rows;

@@ -4,6 +4,11 @@
 // (preprocessCUDA + computeColorFromSH + computeCov3D, backward.cu:20-139,278-396) in ONE pass.
 // Every output element is written exactly once (zeros for culled Gaussians), so the 300 B/Gaussian of
 // torch::zeros the reference needs per call (rasterize_points.cu:151-159) disappear.
+//
+// SH rows are 192 B per Gaussian (AoS, [P][16][3]): read or written per thread they cost one memory instruction per
+// dword with 64 distinct cache lines each.  The workgroup therefore moves its 256 rows through LDS: coalesced 16-byte
+// loads of the SH tile in, per-thread reads with an odd row stride (bank-conflict free), the dL/dSH rows written back
+// into the same LDS tile and streamed out with coalesced 16-byte stores.
 #include "common.h"
 
 namespace {
@@ -16,45 +21,114 @@ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
                                 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                 -0.5900435899266435f};
 
-__global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardArgs a, float h_x, float h_y)
+// The argument struct cannot carry __restrict__; without it every output store would fence the loads behind it
+// (the compiler must assume dL_d* may alias shs / viewmatrix / ...), serialising ~10 HBM round trips per wave.
+struct GaussBackwardPtrs {
+    const float* __restrict__ means3D; const float* __restrict__ shs; const float* __restrict__ scales;
+    const float* __restrict__ rotations; const float* __restrict__ cov3D_in; const float* __restrict__ viewmatrix;
+    const float* __restrict__ projmatrix; const float* __restrict__ campos; const int* __restrict__ radii;
+    const uint8_t* __restrict__ clamped; const float* __restrict__ splat; const uint32_t* __restrict__ tiles_touched;
+    const float* __restrict__ grad_rows; const uint32_t* __restrict__ point_offsets;
+    float* __restrict__ dL_dmeans2D; float* __restrict__ dL_dcolors; float* __restrict__ dL_dopacity;
+    float* __restrict__ dL_dmeans3D; float* __restrict__ dL_dcov3D; float* __restrict__ dL_dsh; float* __restrict__ dL_dscales;
+    float* __restrict__ dL_drots;
+    int P, D, M, has_shs, has_scales, dbg, lds_floats;
+    float scale_modifier, tan_fovx, tan_fovy;
+};
+
+// Moves the workgroup's [rows][3M] tile between global memory and LDS (row stride `stride` floats in LDS).
+__device__ __forceinline__ void sh_tile_load(const float* __restrict__ g, float* __restrict__ s, int rows, int n3, int stride)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-    const int M = a.M;
-    float* o_m2 = a.dL_dmeans2D + 3 * (size_t)idx;
-    float* o_col = a.dL_dcolors + 3 * (size_t)idx;
-    float* o_m3 = a.dL_dmeans3D + 3 * (size_t)idx;
-    float* o_cov = a.dL_dcov3D + 6 * (size_t)idx;
-    float* o_sh = a.dL_dsh + (size_t)idx * M * 3;
-    float* o_sc = a.dL_dscales + 3 * (size_t)idx;
-    float* o_rot = a.dL_drots + 4 * (size_t)idx;
-
-    if (!(a.radii[idx] > 0)) {
-        o_m2[0] = 0.f; o_m2[1] = 0.f; o_m2[2] = 0.f;
-        o_col[0] = 0.f; o_col[1] = 0.f; o_col[2] = 0.f;
-        a.dL_dopacity[idx] = 0.f;
-        o_m3[0] = 0.f; o_m3[1] = 0.f; o_m3[2] = 0.f;
-        for (int i = 0; i < 6; i++) o_cov[i] = 0.f;
-        for (int i = 0; i < 3 * M; i++) o_sh[i] = 0.f;
-        o_sc[0] = 0.f; o_sc[1] = 0.f; o_sc[2] = 0.f;
-        reinterpret_cast<float4*>(o_rot)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-
-    // ---- sum this Gaussian's gradient rows (fixed order -> reproducible) ----
-    float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {
-        const float* rec = a.splat + (size_t)idx * GSR_SPLAT_F;
-        const uint32_t off = __float_as_uint(rec[SP_OFFS]);
-        const uint32_t n = a.tiles_touched[idx];
-        const float4* rows = reinterpret_cast<const float4*>(a.grad_rows + (size_t)off * GSR_GROW_F);
-        for (uint32_t t = 0; t < n; t++) {
-            const float4 r0 = rows[3 * t], r1 = rows[3 * t + 1], r2 = rows[3 * t + 2];
-            g[0] += r0.x; g[1] += r0.y; g[2] += r0.z; g[3] += r0.w;
-            g[4] += r1.x; g[5] += r1.y; g[6] += r1.z; g[7] += r1.w;
-            g[8] += r2.x;
+    const int count = rows * n3;
+    if ((n3 & 3) == 0) {
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        for (int f = threadIdx.x; f < (count >> 2); f += 256) {
+            const float4 v = g4[f];
+            const int e = f << 2, r = e / n3, c = e - r * n3;
+            float* d = s + r * stride + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int e = threadIdx.x; e < count; e += 256) {
+            const int r = e / n3, c = e - r * n3;
+            s[r * stride + c] = g[e];
         }
     }
+}
+__device__ __forceinline__ void sh_tile_store(float* __restrict__ g, const float* __restrict__ s, int rows, int n3, int stride)
+{
+    const int count = rows * n3;
+    if ((n3 & 3) == 0) {
+        float4* g4 = reinterpret_cast<float4*>(g);
+        for (int f = threadIdx.x; f < (count >> 2); f += 256) {
+            const int e = f << 2, r = e / n3, c = e - r * n3;
+            const float* d = s + r * stride + c;
+            g4[f] = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    } else {
+        for (int e = threadIdx.x; e < count; e += 256) {
+            const int r = e / n3, c = e - r * n3;
+            g[e] = s[r * stride + c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
+{
+    extern __shared__ float s_tile[];  // [256][3M + 1]
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int M = a.M, n3 = 3 * M, stride = n3 + 1;
+    const int rows = min(256, a.P - (int)blockIdx.x * 256);
+    const size_t tile_base = (size_t)blockIdx.x * 256 * n3;
+    const bool valid = idx < a.P;
+    const bool visible = valid && a.radii[idx] > 0;
+
+    // ---- sum each Gaussian's gradient rows ----
+    // The rows of this workgroup's Gaussians are one contiguous range of grad_rows (emission order).  They are streamed
+    // through LDS in chunks with coalesced 16-byte loads; every thread then adds the rows of its own Gaussian from LDS in
+    // ascending row order (fixed order -> bitwise reproducible).  Reading them per thread straight from HBM serialises
+    // one dependent round trip per row and was 60 % of this kernel.
+    float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        const int first = blockIdx.x * 256, last = min(a.P, first + 256);
+        const uint32_t begin = first == 0 ? 0u : a.point_offsets[first - 1];
+        const uint32_t end = (a.dbg & 1) ? begin : a.point_offsets[last - 1];
+        uint32_t my_off = 0, my_n = 0;
+        if (visible) {
+            my_off = __float_as_uint(a.splat[(size_t)idx * GSR_SPLAT_F + SP_OFFS]);
+            my_n = a.tiles_touched[idx];
+        }
+        const uint32_t CH = (uint32_t)a.lds_floats / GSR_GROW_F;  // rows per chunk
+        float4* s_rows = reinterpret_cast<float4*>(s_tile);
+        const float4* g4 = reinterpret_cast<const float4*>(a.grad_rows);
+        for (uint32_t cb = begin; cb < end; cb += CH) {
+            const uint32_t nrows = min(CH, end - cb);
+            for (uint32_t f = threadIdx.x; f < nrows * 3; f += 256) s_rows[f] = g4[(size_t)cb * 3 + f];
+            __syncthreads();
+            const uint32_t lo = max(my_off, cb), hi = min(my_off + my_n, cb + nrows);
+            for (uint32_t r = lo; r < hi; r++) {
+                const float4 r0 = s_rows[(r - cb) * 3], r1 = s_rows[(r - cb) * 3 + 1], r2 = s_rows[(r - cb) * 3 + 2];
+                g[0] += r0.x; g[1] += r0.y; g[2] += r0.z; g[3] += r0.w;
+                g[4] += r1.x; g[5] += r1.y; g[6] += r1.z; g[7] += r1.w;
+                g[8] += r2.x;
+            }
+            __syncthreads();
+        }
+    }
+
+    if (a.has_shs && !(a.dbg & 2)) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
+    __syncthreads();
+    float* __restrict__ my_row = s_tile + threadIdx.x * stride;  // SH in, dL/dSH out
+
+    if (visible) {
+    float* __restrict__ o_m2 = a.dL_dmeans2D + 3 * (size_t)idx;
+    float* __restrict__ o_col = a.dL_dcolors + 3 * (size_t)idx;
+    float* __restrict__ o_m3 = a.dL_dmeans3D + 3 * (size_t)idx;
+    float* __restrict__ o_cov = a.dL_dcov3D + 6 * (size_t)idx;
+    float* __restrict__ o_sh = my_row;
+    float* __restrict__ o_sc = a.dL_dscales + 3 * (size_t)idx;
+    float* __restrict__ o_rot = a.dL_drots + 4 * (size_t)idx;
+
     const float dL_dmean2D_x = g[GR_MX], dL_dmean2D_y = g[GR_MY];
     const float dLc_x = g[GR_CX], dLc_y = g[GR_CY], dLc_w = g[GR_CW];
     float dL_dcol[3] = {g[GR_R], g[GR_G], g[GR_B]};
@@ -151,38 +225,27 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardArg
         const float dox = mx - a.campos[0], doy = my - a.campos[1], doz = mz - a.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
-        const float* sh = a.shs + (size_t)idx * M * 3;
+        const float* sh = my_row;
         float dRGB[3];
         for (int ch = 0; ch < 3; ch++) dRGB[ch] = dL_dcol[ch] * (a.clamped[3 * idx + ch] ? 0.f : 1.f);
         float dx_[3] = {0, 0, 0}, dy_[3] = {0, 0, 0}, dz_[3] = {0, 0, 0};
 #define SH(i) sh[3 * (i) + ch]
 #define OUT(i, w) { const float w_ = (w); o_sh[3 * (i)] = w_ * dRGB[0]; o_sh[3 * (i) + 1] = w_ * dRGB[1]; o_sh[3 * (i) + 2] = w_ * dRGB[2]; }
-        OUT(0, bSH_C0);
-        int written = 1;
+        // first every read of the SH row (it is overwritten in place by dL/dSH below)
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
         if (deg > 0) {
-            OUT(1, -bSH_C1 * y); OUT(2, bSH_C1 * z); OUT(3, -bSH_C1 * x);
-            written = 4;
             for (int ch = 0; ch < 3; ch++) {
                 dx_[ch] = -bSH_C1 * SH(3);
                 dy_[ch] = -bSH_C1 * SH(1);
                 dz_[ch] = bSH_C1 * SH(2);
             }
             if (deg > 1) {
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                OUT(4, bSH_C2[0] * xy); OUT(5, bSH_C2[1] * yz); OUT(6, bSH_C2[2] * (2.f * zz - xx - yy));
-                OUT(7, bSH_C2[3] * xz); OUT(8, bSH_C2[4] * (xx - yy));
-                written = 9;
                 for (int ch = 0; ch < 3; ch++) {
                     dx_[ch] += bSH_C2[0] * y * SH(4) + bSH_C2[2] * 2.f * -x * SH(6) + bSH_C2[3] * z * SH(7) + bSH_C2[4] * 2.f * x * SH(8);
                     dy_[ch] += bSH_C2[0] * x * SH(4) + bSH_C2[1] * z * SH(5) + bSH_C2[2] * 2.f * -y * SH(6) + bSH_C2[4] * 2.f * -y * SH(8);
                     dz_[ch] += bSH_C2[1] * y * SH(5) + bSH_C2[2] * 2.f * 2.f * z * SH(6) + bSH_C2[3] * x * SH(7);
                 }
                 if (deg > 2) {
-                    OUT(9, bSH_C3[0] * y * (3.f * xx - yy)); OUT(10, bSH_C3[1] * xy * z);
-                    OUT(11, bSH_C3[2] * y * (4.f * zz - xx - yy)); OUT(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-                    OUT(13, bSH_C3[4] * x * (4.f * zz - xx - yy)); OUT(14, bSH_C3[5] * z * (xx - yy));
-                    OUT(15, bSH_C3[6] * x * (xx - 3.f * yy));
-                    written = 16;
                     for (int ch = 0; ch < 3; ch++) {
                         dx_[ch] += (bSH_C3[0] * SH(9) * 3.f * 2.f * xy + bSH_C3[1] * SH(10) * yz + bSH_C3[2] * SH(11) * -2.f * xy +
                                     bSH_C3[3] * SH(12) * -3.f * 2.f * xz + bSH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
@@ -195,6 +258,25 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardArg
                                     bSH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + bSH_C3[4] * SH(13) * 4.f * 2.f * xz +
                                     bSH_C3[5] * SH(14) * (xx - yy));
                     }
+                }
+            }
+        }
+        // then dL/dSH = dRGB/dSH * dL/dRGB into the same row
+        OUT(0, bSH_C0);
+        int written = 1;
+        if (deg > 0) {
+            OUT(1, -bSH_C1 * y); OUT(2, bSH_C1 * z); OUT(3, -bSH_C1 * x);
+            written = 4;
+            if (deg > 1) {
+                OUT(4, bSH_C2[0] * xy); OUT(5, bSH_C2[1] * yz); OUT(6, bSH_C2[2] * (2.f * zz - xx - yy));
+                OUT(7, bSH_C2[3] * xz); OUT(8, bSH_C2[4] * (xx - yy));
+                written = 9;
+                if (deg > 2) {
+                    OUT(9, bSH_C3[0] * y * (3.f * xx - yy)); OUT(10, bSH_C3[1] * xy * z);
+                    OUT(11, bSH_C3[2] * y * (4.f * zz - xx - yy)); OUT(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                    OUT(13, bSH_C3[4] * x * (4.f * zz - xx - yy)); OUT(14, bSH_C3[5] * z * (xx - yy));
+                    OUT(15, bSH_C3[6] * x * (xx - 3.f * yy));
+                    written = 16;
                 }
             }
         }
@@ -247,6 +329,23 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardArg
         o_sc[0] = 0.f; o_sc[1] = 0.f; o_sc[2] = 0.f;
         reinterpret_cast<float4*>(o_rot)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    } else if (valid) {  // culled: every output is zero
+        float* __restrict__ o_m2 = a.dL_dmeans2D + 3 * (size_t)idx;
+        float* __restrict__ o_col = a.dL_dcolors + 3 * (size_t)idx;
+        float* __restrict__ o_m3 = a.dL_dmeans3D + 3 * (size_t)idx;
+        float* __restrict__ o_cov = a.dL_dcov3D + 6 * (size_t)idx;
+        float* __restrict__ o_sc = a.dL_dscales + 3 * (size_t)idx;
+        o_m2[0] = 0.f; o_m2[1] = 0.f; o_m2[2] = 0.f;
+        o_col[0] = 0.f; o_col[1] = 0.f; o_col[2] = 0.f;
+        a.dL_dopacity[idx] = 0.f;
+        o_m3[0] = 0.f; o_m3[1] = 0.f; o_m3[2] = 0.f;
+        for (int i = 0; i < 6; i++) o_cov[i] = 0.f;
+        for (int i = 0; i < n3; i++) my_row[i] = 0.f;
+        o_sc[0] = 0.f; o_sc[1] = 0.f; o_sc[2] = 0.f;
+        reinterpret_cast<float4*>(a.dL_drots + 4 * (size_t)idx)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (n3 > 0 && !(a.dbg & 4)) sh_tile_store(a.dL_dsh + tile_base, s_tile, rows, n3, stride);
 }
 
 }  // namespace
@@ -255,5 +354,17 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
 {
     const float h_y = a.H / (2.0f * a.tan_fovy);  // rasterizer_impl.cu:381-382
     const float h_x = a.W / (2.0f * a.tan_fovx);
-    hipLaunchKernelGGL(gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, h_x, h_y);
+    GaussBackwardPtrs p;
+    p.means3D = a.means3D; p.shs = a.shs; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_in = a.cov3D_in;
+    p.viewmatrix = a.viewmatrix; p.projmatrix = a.projmatrix; p.campos = a.campos; p.radii = a.radii; p.clamped = a.clamped;
+    p.splat = a.splat; p.tiles_touched = a.tiles_touched; p.grad_rows = a.grad_rows; p.point_offsets = a.point_offsets;
+    p.dL_dmeans2D = a.dL_dmeans2D; p.dL_dcolors = a.dL_dcolors; p.dL_dopacity = a.dL_dopacity; p.dL_dmeans3D = a.dL_dmeans3D;
+    p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscales = a.dL_dscales; p.dL_drots = a.dL_drots;
+    p.P = a.P; p.D = a.D; p.M = a.M; p.has_shs = a.has_shs; p.has_scales = a.has_scales;
+    p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
+    p.dbg = gsr_variant("GB_DBG", 0);
+    size_t lds = (size_t)256 * (3 * a.M + 1) * 4;
+    if (lds < 1024 * GSR_GROW_F * 4) lds = 1024 * GSR_GROW_F * 4;  // room for 1024 gradient rows per chunk
+    p.lds_floats = (int)(lds / 4);
+    hipLaunchKernelGGL(gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
 }

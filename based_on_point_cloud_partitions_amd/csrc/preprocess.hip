@@ -54,7 +54,20 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, const float* __restrict__ sh, F
 // One thread per Gaussian, 256 per workgroup (4 waves).  Streams xyz/scale/rot/opacity/SH once,
 // writes one 48-byte splat record + cov3D + clamped + tiles_touched, and the workgroup's
 // tiles_touched sum (feeds the two-level prefix sum without an extra pass over P).
-__global__ void __launch_bounds__(256) preprocess_kernel(PreprocessArgs a, float focal_x, float focal_y, int gx, int gy)
+// Kernel-side copy of PreprocessArgs with __restrict__ pointers: lets the compiler hoist the input loads over the output
+// stores and read the camera matrices with scalar loads.
+struct PreprocessPtrs {
+    int P, D, M, W, H;
+    const float* __restrict__ means3D; const float* __restrict__ scales; const float* __restrict__ rotations;
+    const float* __restrict__ opacities; const float* __restrict__ shs; const float* __restrict__ cov3D_precomp;
+    const float* __restrict__ colors_precomp; const float* __restrict__ viewmatrix; const float* __restrict__ projmatrix;
+    const float* __restrict__ campos;
+    float scale_modifier, tan_fovx, tan_fovy;
+    int* __restrict__ radii; float* __restrict__ splat; float* __restrict__ cov3D; uint8_t* __restrict__ clamped;
+    uint32_t* __restrict__ tiles_touched; uint32_t* __restrict__ block_sums;
+};
+
+__global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float focal_x, float focal_y, int gx, int gy)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     uint32_t touched = 0;
@@ -279,7 +292,15 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     const float focal_y = a.H / (2.0f * a.tan_fovy);  // rasterizer_impl.cu:222-223
     const float focal_x = a.W / (2.0f * a.tan_fovx);
     const int gx = (a.W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, focal_x, focal_y, gx, gy);
+    PreprocessPtrs p;
+    p.P = a.P; p.D = a.D; p.M = a.M; p.W = a.W; p.H = a.H;
+    p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.opacities = a.opacities; p.shs = a.shs;
+    p.cov3D_precomp = a.cov3D_precomp; p.colors_precomp = a.colors_precomp; p.viewmatrix = a.viewmatrix;
+    p.projmatrix = a.projmatrix; p.campos = a.campos;
+    p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
+    p.radii = a.radii; p.splat = a.splat; p.cov3D = a.cov3D; p.clamped = a.clamped; p.tiles_touched = a.tiles_touched;
+    p.block_sums = a.block_sums;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, focal_x, focal_y, gx, gy);
 }
 
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, hipStream_t s)

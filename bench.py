@@ -207,7 +207,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    roofline["traffic"] = json.load(open(pmc)).get(d["kernel"])
+                    roofline["traffic"] = json.load(open(pmc)).get(d["kernel"], {}).get("hbm_bytes")
                 except Exception:
                     pass
         fwd_ms = sum(k["avg_ms"] for k in kernels if k["kernel"] in

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Turns the two rocprofv3 --pmc passes of profiles/collect.sh into profiles/pmc_traffic.json.
+
+HBM traffic per launch and stage = 2 x FETCH_SIZE + WRITE_SIZE.  Units and correction follow
+MI355X_MICROARCH.md §HBM: rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests
+of 16-byte-per-lane loads at 64 bytes, i.e. exactly half the bytes, so it is doubled (every global load of the hot
+kernels is a 16-byte-per-lane load); WRITE_SIZE is exact for 16-byte stores.  Counters are averaged over the launches
+of each kernel in the timed bench and the kernels of one stage are summed.
+usage: pmc_to_json.py <dir with fetch_counter_collection.csv / write_counter_collection.csv> <out.json>
+"""
+import collections
+import csv
+import json
+import sys
+
+STAGE = {
+    "preprocess_kernel": "preprocess", "scan_blocks_kernel": "scan", "emit_keys_kernel": "emit_keys",
+    "tile_count_kernel": "radix_sort", "tile_colscan_kernel": "radix_sort", "tile_starts_kernel": "radix_sort",
+    "tile_scatter_kernel": "radix_sort", "tile_sort_kernel": "radix_sort", "global_hist_kernel": "radix_sort",
+    "block_hist_kernel": "radix_sort", "bin_scan_kernel": "radix_sort", "scatter_kernel": "radix_sort",
+    "tile_ranges_kernel": "tile_ranges", "render_forward_kernel": "render_forward", "render_backward_kernel": "render_backward",
+    "gaussian_backward_kernel": "gaussian_backward",
+}
+
+
+def load(path, counter):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+        per[name].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in per.items()}
+
+
+def main(d, out):
+    f = load(f"{d}/fetch_counter_collection.csv", "FETCH_SIZE")
+    w = load(f"{d}/write_counter_collection.csv", "WRITE_SIZE")
+    res = collections.defaultdict(lambda: {"fetch_size_kib": 0.0, "write_size_kib": 0.0})
+    launches_per_step = {"block_hist_kernel": 6, "bin_scan_kernel": 6, "scatter_kernel": 6}
+    for k, st in STAGE.items():
+        mult = launches_per_step.get(k, 1)
+        if k in f:
+            res[st]["fetch_size_kib"] += f[k] * mult
+        if k in w:
+            res[st]["write_size_kib"] += w[k] * mult
+    outd = {}
+    for st, v in res.items():
+        outd[st] = {"hbm_bytes": int((2 * v["fetch_size_kib"] + v["write_size_kib"]) * 1024), **{a: round(b, 1) for a, b in v.items()},
+                    "formula": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM"}
+    json.dump(outd, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v["hbm_bytes"] for k, v in outd.items()}))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
