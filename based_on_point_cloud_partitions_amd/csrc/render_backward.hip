@@ -118,8 +118,9 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
 {
     constexpr int ACC_STRIDE = BATCH * NV;  // floats per wave
     __shared__ float4 s_a[BATCH];  // mx, my, conic.x, conic.y
-    __shared__ float4 s_b[BATCH];  // conic.z, opacity, pthr, row index (uint bits)
-    __shared__ float4 s_c[BATCH];  // r, g, b, -
+    __shared__ float4 s_b[BATCH];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
+    __shared__ float4 s_c[BATCH];  // r, g, b, gradient row index (uint bits)
+    __shared__ int s_wcnt[4];      // entries each wave keeps after the tile-level rejection
     __shared__ __attribute__((aligned(16))) float s_acc[4 * ACC_STRIDE];
     __shared__ uint32_t s_max[4];
 
@@ -130,6 +131,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
     const size_t pix_id = (size_t)W * pix_y + pix_x;
     const size_t plane = (size_t)H * W;
     const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+    const float tile_x0 = (float)(blockIdx.x * GSR_TILE_X), tile_y0 = (float)(blockIdx.y * GSR_TILE_Y);
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
     const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const uint32_t total = r1 - r0;
@@ -161,20 +163,40 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
     const int my_slot = lane < 8 ? (4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1)) : 8;
 
     for (int i = 0; i < rounds; i++) {
-        __syncthreads();  // previous batch fully flushed
+        // gather this batch's records (back to front); entries the tile cannot see at all (gsr_tile_cannot_touch) get their
+        // zero gradient row right here and are dropped from the walk
         const uint32_t progress = (uint32_t)i * BATCH + tid;
+        bool keep = false;
+        float4 q0, q1, q2;
+        float pthr = 0.f;
+        uint32_t k = 0, row = 0;
         if (tid < BATCH && progress < hi) {
-            const uint32_t k = hi - 1 - progress;
+            k = hi - 1 - progress;
             const uint32_t id = point_list[r0 + k];
             const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
             uint32_t mnx, mny, mxx, mxy;
             gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
-            const uint32_t row = __float_as_uint(q2.w) + (blockIdx.y - mny) * (mxx - mnx) + (blockIdx.x - mnx);
-            const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
-            s_a[tid] = q0;
-            s_b[tid] = make_float4(q1.x, q1.y, pthr, __uint_as_float(row));
-            s_c[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
+            row = __float_as_uint(q2.w) + (blockIdx.y - mny) * (mxx - mnx) + (blockIdx.x - mnx);
+            pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
+            keep = !gsr_tile_cannot_touch(q0.x, q0.y, q0.z, q0.w, q1.x, pthr, tile_x0, tile_y0);
+            if (!keep) {
+                float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                o[0] = z; o[1] = z; o[2] = z;
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();  // previous batch fully flushed; counts visible
+        int base = 0;
+        for (int w = 0; w < wave; w++) base += s_wcnt[w];
+        const int nb = __builtin_amdgcn_readfirstlane(s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
+        if (keep) {  // order-preserving compaction
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            s_a[pos] = q0;
+            s_b[pos] = make_float4(q1.x, q1.y, pthr, __uint_as_float(k));
+            s_c[pos] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(row));
         }
         {   // zero this wave's accumulators
             float4* z = reinterpret_cast<float4*>(my_acc);
@@ -183,12 +205,11 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
                 if (t * 64 + lane < ACC_STRIDE / 4) z[t * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        const int nb = (int)min((uint32_t)BATCH, hi - (uint32_t)i * BATCH);
 #pragma unroll 2
         for (int j = 0; j < nb; j++) {
-            const uint32_t kidx = hi - 1 - ((uint32_t)i * BATCH + j);
             const float4 a = s_a[j];
             const float4 b = s_b[j];
+            const uint32_t kidx = __float_as_uint(b.w);  // position of this entry in the tile's list
             // entries behind this pixel's last contributor are parked far away (power -> -inf / NaN), so one range test
             // covers `kidx < last_contributor`, `power <= 0` and the conservative alpha < 1/255 shortcut
             const float px = kidx < last_contributor ? pixf_x : 1e30f;
@@ -252,7 +273,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             const float gmx = op * (-cx * r[1] - cy * r[2]) * ddelx_dx;
             const float gmy = op * (-cz * r[2] - cy * r[1]) * ddely_dy;
             const float hop = -0.5f * op;
-            const uint32_t row = __float_as_uint(b.w);
+            const uint32_t row = __float_as_uint(s_c[tid].w);
             float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
             o[0] = make_float4(gmx, gmy, hop * r[3], hop * r[4]);
             o[1] = make_float4(hop * r[5], r[0], r[6], r[7]);

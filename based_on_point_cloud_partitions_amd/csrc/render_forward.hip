@@ -20,13 +20,15 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                              float* __restrict__ out_color)
 {
-    __shared__ float4 s_a[256];  // mx, my, conic.x, conic.y
-    __shared__ float4 s_b[256];  // conic.z, opacity, pthr, -
+    __shared__ float4 s_a[260];  // mx, my, conic.x, conic.y          (+4: padding entries for the unrolled walk)
+    __shared__ float4 s_b[260];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
     __shared__ float4 s_c[256];  // r, g, b, -
     __shared__ int s_done[4];
+    __shared__ int s_wcnt[4];    // entries each wave keeps after the tile-level rejection
 
     const uint32_t tile = blockIdx.y * gx + blockIdx.x;
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float tile_x0 = (float)(blockIdx.x * GSR_TILE_X), tile_y0 = (float)(blockIdx.y * GSR_TILE_Y);
     const uint32_t pix_x = blockIdx.x * GSR_TILE_X + (tid & 15), pix_y = blockIdx.y * GSR_TILE_Y + (tid >> 4);
     const bool inside = pix_x < (uint32_t)W && pix_y < (uint32_t)H;
     const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
@@ -45,29 +47,40 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     bool wave_done = __ballot(px != PARKED) == 0ull;
 
     for (int i = 0; i < rounds; i++) {
-        // workgroup-wide early exit (forward.cu:301-304)
-        if ((tid & 63) == 0) s_done[wave] = wave_done;
-        __syncthreads();
-        if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
+        // gather this batch's records and decide, per entry, whether the tile can see it at all
         const int progress = i * 256 + tid;
+        bool keep = false;
+        float4 q0, q1, q2;
+        float pthr = 0.f;
         if (progress < total) {
             const uint32_t id = point_list[r0 + progress];
             const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
             // conservative skip threshold on `power` (see header); opacity <= 0 or NaN never skips
-            const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
-            s_a[tid] = q0;
-            s_b[tid] = make_float4(q1.x, q1.y, pthr, 0.f);
-            s_c[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
-        } else {
-            // padding entry that can never pass the range test (lets the hot loop run in groups of 4 without bounds checks)
-            s_a[tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
-            s_b[tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
+            pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
+            keep = !gsr_tile_cannot_touch(q0.x, q0.y, q0.z, q0.w, q1.x, pthr, tile_x0, tile_y0);
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) { s_done[wave] = wave_done; s_wcnt[wave] = __popcll(bal); }
+        __syncthreads();  // previous batch fully consumed; counts and done flags visible
+        // workgroup-wide early exit (forward.cu:301-304)
+        if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
+        int base = 0;
+        for (int w = 0; w < wave; w++) base += s_wcnt[w];
+        const int kept = __builtin_amdgcn_readfirstlane(s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
+        if (keep) {  // order-preserving compaction (the walk must stay front to back)
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            s_a[pos] = q0;
+            s_b[pos] = make_float4(q1.x, q1.y, pthr, __uint_as_float((uint32_t)progress));
+            s_c[pos] = make_float4(q1.z, q1.w, q2.x, 0.f);
+        }
+        if (tid < 4) {  // padding entries that can never pass the range test (walk runs in groups of 4, no bounds checks)
+            s_a[kept + tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
+            s_b[kept + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
         }
         __syncthreads();
         if (!wave_done) {
-            const int nb = min(256, total - i * 256);
-            for (int j0 = 0; j0 < nb; j0 += 4) {
+            for (int j0 = 0; j0 < kept; j0 += 4) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int j = j0 + u;
@@ -93,7 +106,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                     C1 = __builtin_fmaf(c.y * alpha, T, C1);
                                     C2 = __builtin_fmaf(c.z * alpha, T, C2);
                                     T = test_T;
-                                    last_contributor = (uint32_t)(i * 256 + j + 1);  // = `contributor` of forward.cu:322
+                                    last_contributor = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
                                 }
                             }
                         }

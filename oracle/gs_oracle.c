@@ -403,15 +403,15 @@ static inline int blend_pair(const float* xy, const float* con_o, float pixx, fl
 
 /* K7 renderCUDA forward, forward.cu:261-374.  Per-pixel loops (the block-wide
  * early exit of :301-304 does not change any per-pixel result).
- * stats (optional, 3 x int64): [0] visited pairs, [1] blended pairs, [2] (list entry, 16x4 pixel strip) instances with
+ * stats (optional, 4 x int64; [3] = list entries with at least one blended pixel in their tile): [0] visited pairs, [1] blended pairs, [2] (list entry, 16x4 pixel strip) instances with
  * at least one blended pixel -- the unit of work of the GPU blend kernels' slow path. */
 void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
                         const float* features, const float* conic_opacity, const float* bg,
                         /* out */ float* final_T, uint32_t* n_contrib, float* out_color, long long* stats)
 {
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
-    long long visited = 0, blended = 0, strips = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : visited, blended, strips)
+    long long visited = 0, blended = 0, strips = 0, touched = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : visited, blended, strips, touched)
     for (int tile = 0; tile < gx * gy; tile++) {
         int ty = tile / gx, tx = tile % gx;
         uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
@@ -446,11 +446,11 @@ void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* po
                     out_color[(size_t)ch * H * W + pix_id] = C[ch] + T * bg[ch];
             }
         if (sflag) {
-            for (uint32_t k = 0; k < r1 - r0; k++) strips += __builtin_popcount(sflag[k]);
+            for (uint32_t k = 0; k < r1 - r0; k++) { strips += __builtin_popcount(sflag[k]); if (sflag[k]) touched++; }
             free(sflag);
         }
     }
-    if (stats) { stats[0] = visited; stats[1] = blended; stats[2] = strips; }
+    if (stats) { stats[0] = visited; stats[1] = blended; stats[2] = strips; stats[3] = touched; }
 }
 
 /* K8 renderCUDA backward, backward.cu:399-557.  The reference accumulates the 9
