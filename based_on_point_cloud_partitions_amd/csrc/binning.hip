@@ -10,8 +10,9 @@
 //   3. tile_starts:  exclusive scan of the totals -> tile ranges (the reference's `ranges`, empty tiles stay (0,0));
 //   4. tile_scatter: same slicing as (1); an LDS cursor per tile hands out slots, (depth bits, id) pairs go straight
 //                    into their tile's segment (8 B/instance, written once);
-//   5. tile_sort:    one workgroup per tile sorts its segment by (depth, id) in LDS with a normalized bitonic network
-//                    (all comparators ascending, so the tail is padded virtually) and writes point_list (+ keys).
+//   5. tile_sort:    one workgroup per tile sorts its segment by (depth, id) in LDS -- bucket sort + insertion sort for
+//                    lists up to 1024 entries, a normalized bitonic network (all comparators ascending, tail padded
+//                    virtually) for longer ones -- and writes point_list (+ keys).
 // The order in which (4) fills a segment is arbitrary (LDS atomics), but ids are unique within a tile, so the sorted
 // result is unique: ascending depth bits, ties by ascending id = the stable sort's emission order.
 // Integer/byte work, HBM + LDS bound; no MFMA.
@@ -205,23 +206,149 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr a, uint32_t n, uint32_t N
     __syncthreads();
 }
 
-// (5) one workgroup per tile.
-__global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ bins,
-                                                        uint32_t* __restrict__ point_list, unsigned long long* __restrict__ keys_sorted)
+// (5a) one workgroup per tile, lists of up to BUCKET_CAP entries (the common case): bucket sort in LDS.
+// Depth bits are mapped monotonically onto N buckets (N = pow2 >= n, so ~1 entry per bucket), a counting sort places
+// the keys bucket by bucket, and each thread finishes a few adjacent buckets with an insertion sort on the full 64-bit
+// (depth, id) key.  ~10 LDS operations per entry instead of the ~100 of a bitonic network (which is what limited the
+// first version: it was LDS-bandwidth bound).  A bucket that grows past BUCKET_LIMIT (many equal depths) sends the
+// tile to the bitonic path, so the worst case stays n log^2 n.
+constexpr int BUCKET_CAP = 1024;
+constexpr int BUCKET_LIMIT = 16;
+constexpr int BUCKET_EPT = BUCKET_CAP / 256;  // entries / buckets per thread
+
+__global__ void __launch_bounds__(256) tile_sort_small_kernel(const uint32_t* __restrict__ ranges,
+                                                              const unsigned long long* __restrict__ bins,
+                                                              uint32_t* __restrict__ point_list,
+                                                              unsigned long long* __restrict__ keys_sorted)
+{
+    __shared__ unsigned long long s_keys[BUCKET_CAP];
+    __shared__ uint32_t s_cnt[BUCKET_CAP + 1];
+    __shared__ uint32_t s_red[8];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ int s_overflow;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+    const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
+    const uint32_t n = r1 - r0;
+    if (n == 0 || n > BUCKET_CAP) return;  // empty, or handled by tile_sort_large_kernel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t N = 1;
+    while (N < n) N <<= 1;
+    const unsigned long long* seg = bins + r0;
+    unsigned long long key[BUCKET_EPT];
+    uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+#pragma unroll
+    for (int e = 0; e < BUCKET_EPT; e++) {
+        const uint32_t i = tid + 256 * e;
+        key[e] = i < n ? seg[i] : ~0ull;
+        if (i < n) { const uint32_t d = (uint32_t)(key[e] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, off, 64));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
+    }
+    if (lane == 0) { s_red[wave] = dmin; s_red[4 + wave] = dmax; }
+    for (uint32_t b = tid; b <= N; b += 256) s_cnt[b] = 0;
+    if (tid == 0) s_overflow = 0;
+    __syncthreads();
+    dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    // monotone map depth bits -> bucket (float rounding is monotone, so equal or larger depth never gets a smaller bucket)
+    const float inv = (float)N / ((float)(dmax - dmin) + 1.0f);
+    uint32_t bucket[BUCKET_EPT];
+#pragma unroll
+    for (int e = 0; e < BUCKET_EPT; e++) {
+        const uint32_t i = tid + 256 * e;
+        bucket[e] = 0;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[e] >> 32);
+            bucket[e] = min(N - 1, (uint32_t)((float)(d - dmin) * inv));
+            atomicAdd(&s_cnt[bucket[e]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the N bucket counts: thread t owns buckets [t*EPT, t*EPT + EPT)
+    uint32_t c[BUCKET_EPT], tsum = 0;
+#pragma unroll
+    for (int e = 0; e < BUCKET_EPT; e++) {
+        const uint32_t b = tid * BUCKET_EPT + e;
+        c[e] = b < N ? s_cnt[b] : 0u;
+        tsum += c[e];
+    }
+    uint32_t incl = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t start = incl - tsum;
+    for (int w = 0; w < wave; w++) start += s_wsum[w];
+    uint32_t bstart[BUCKET_EPT];
+    bool big = false;
+#pragma unroll
+    for (int e = 0; e < BUCKET_EPT; e++) {
+        const uint32_t b = tid * BUCKET_EPT + e;
+        bstart[e] = start;
+        if (b < N) s_cnt[b] = start;  // becomes the bucket's write cursor
+        start += c[e];
+        big |= c[e] > BUCKET_LIMIT;
+    }
+    if (big) s_overflow = 1;
+    __syncthreads();
+    if (s_overflow) {
+        // degenerate depth distribution: sort the whole list with the bitonic network instead
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < BUCKET_EPT; e++) {
+            const uint32_t i = tid + 256 * e;
+            if (i < n) s_keys[i] = key[e];
+        }
+        __syncthreads();
+        if (n > 1) bitonic_sort_block<true>(s_keys, n, N);
+    } else {
+#pragma unroll
+        for (int e = 0; e < BUCKET_EPT; e++) {
+            const uint32_t i = tid + 256 * e;
+            if (i < n) s_keys[atomicAdd(&s_cnt[bucket[e]], 1u)] = key[e];
+        }
+        __syncthreads();
+        // insertion sort of this thread's buckets (adjacent, so the union [bstart[0], end) is one contiguous run)
+        const uint32_t lo = bstart[0], hi = start;
+        for (uint32_t i = lo + 1; i < hi; i++) {
+            const unsigned long long x = s_keys[i];
+            uint32_t j = i;
+            while (j > lo && s_keys[j - 1] > x) { s_keys[j] = s_keys[j - 1]; j--; }
+            s_keys[j] = x;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += 256) {
+        const unsigned long long k = s_keys[i];
+        point_list[r0 + i] = (uint32_t)k;
+        if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
+    }
+}
+
+// (5b) one workgroup per tile, lists longer than BUCKET_CAP: bitonic network in LDS (<= SORT_CAP) or in place in HBM.
+__global__ void __launch_bounds__(256) tile_sort_large_kernel(const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ bins,
+                                                              uint32_t* __restrict__ point_list, unsigned long long* __restrict__ keys_sorted)
 {
     __shared__ unsigned long long s_keys[SORT_CAP];
     const uint32_t tile = blockIdx.x;
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
     const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const uint32_t n = r1 - r0;
-    if (n == 0) return;
+    if (n <= BUCKET_CAP) return;
     uint32_t N = 1;
     while (N < n) N <<= 1;
     unsigned long long* seg = bins + r0;
     if (n <= SORT_CAP) {
         for (uint32_t i = threadIdx.x; i < n; i += 256) s_keys[i] = seg[i];
         __syncthreads();
-        if (n > 1) bitonic_sort_block<true>(s_keys, n, N);
+        bitonic_sort_block<true>(s_keys, n, N);
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const unsigned long long k = s_keys[i];
             point_list[r0 + i] = (uint32_t)k;
@@ -266,6 +393,8 @@ void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* 
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(1024), 0, s, T, totals, starts, ranges);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(256), lds, s, P, gpb, gx, gy, T, splat, table, starts,
                        reinterpret_cast<uint2*>(bins));
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<unsigned long long*>(bins), point_list,
+    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<const unsigned long long*>(bins),
+                       point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
+    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<unsigned long long*>(bins), point_list,
                        reinterpret_cast<unsigned long long*>(keys_sorted));
 }

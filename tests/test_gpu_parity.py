@@ -110,6 +110,26 @@ def test_very_long_tile_lists_use_the_in_place_sort_path():
     assert ((ln > 1024) & (ln <= 4096)).any()
 
 
+def test_many_equal_depths_tie_break_by_index():
+    # exact duplicates of positions -> identical depth bits: ties must come out in ascending Gaussian index (the stable
+    # sort's emission order); also drives the per-tile bucket sort into its overflow (bitonic) path
+    import torch
+
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    g, cam = scene(300, 128, 128, 90.0, seed=17, scale_lo=0.05, scale_hi=0.15)
+    rep = 40
+    idx = torch.randperm(300 * rep, generator=torch.Generator().manual_seed(0)) % 300
+    g2 = syn.SyntheticGaussians(g.xyz[idx], g.scales[idx], g.rotations[idx], g.opacities[idx] * 0.2, g.shs[idx])
+    st = oracle_forward(g2, cam, bg=(0.1, 0.1, 0.1))
+    ctx = hip_forward_raw(g2, cam, bg=(0.1, 0.1, 0.1))
+    assert_forward_bit_exact(ctx, st)
+    keys = st["keys_sorted"]
+    assert (keys[1:] == keys[:-1]).mean() > 0.5  # most neighbours in the sorted list are exact ties
+    dL = np.random.default_rng(1).standard_normal((3, 128, 128)).astype(np.float32)
+    assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+
+
 def test_precomputed_colors_and_covariance():
     _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=21, colors=True, cov=True, bg=(0.5, 0.5, 0.5))
     _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=22, colors=True, cov=False)
