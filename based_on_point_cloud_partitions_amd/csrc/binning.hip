@@ -212,7 +212,7 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr a, uint32_t n, uint32_t N
 // (depth, id) key.  ~10 LDS operations per entry instead of the ~100 of a bitonic network (which is what limited the
 // first version: it was LDS-bandwidth bound).  A bucket that grows past BUCKET_LIMIT (many equal depths) sends the
 // tile to the bitonic path, so the worst case stays n log^2 n.
-constexpr int BUCKET_CAP = 1024;
+constexpr int BUCKET_CAP = 2048;
 constexpr int BUCKET_LIMIT = 16;
 constexpr int BUCKET_EPT = BUCKET_CAP / 256;  // entries / buckets per thread
 
