@@ -32,6 +32,9 @@ PROTOTYPES = {
                                      c_void_p, c_size, ctypes.POINTER(c_i64), c_void_p]),
     "gsr_forward_render": (c_int, [c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_size, c_void_p, c_size, c_void_p, c_size,
                                    c_void_p, c_void_p]),
+    "gsr_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_size, c_void_p,
+                            c_size, c_void_p, c_size, c_void_p, ctypes.POINTER(c_i64), c_void_p]),
     "gsr_backward": (c_int, [c_int, c_int, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_size,
                              c_void_p, c_size, c_void_p, c_size, c_void_p, c_size, c_void_p, c_void_p, c_void_p, c_void_p,

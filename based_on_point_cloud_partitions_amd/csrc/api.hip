@@ -56,6 +56,52 @@ struct StageTimer {
     }
 };
 
+// ---- host mailbox for num_rendered -------------------------------------------------------------------------------
+// The forward needs R on the host to size the binning buffer (the reference synchronises at the same point,
+// rasterizer_impl.cu:281).  Instead of hipMemcpyAsync + hipStreamSynchronize (a copy command plus a blocking wait,
+// ~50 us of GPU idle time per step) the prefix-sum kernel publishes R, tagged with a sequence number, in host-mapped
+// pinned memory and the host polls that word.
+constexpr int kMailSlots = 64;
+struct Mailbox { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; };
+Mailbox g_mail[16];
+std::mutex g_mail_mu;
+uint32_t g_mail_seq = 0;
+
+bool mailbox_acquire(unsigned long long** host_slot, unsigned long long** dev_slot, uint32_t* seq)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    std::lock_guard<std::mutex> lk(g_mail_mu);
+    Mailbox& m = g_mail[dev];
+    if (!m.host) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, kMailSlots * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return false; }
+        memset(h, 0, kMailSlots * sizeof(unsigned long long));
+        m.host = (unsigned long long*)h;
+        m.dev = (unsigned long long*)d;
+    }
+    const uint32_t s = ++g_mail_seq;
+    *host_slot = m.host + (s % kMailSlots);
+    *dev_slot = m.dev + (s % kMailSlots);
+    *seq = s;
+    return true;
+}
+
+// Waits for the tagged value; falls back to a stream synchronisation if it does not show up (bounded spin).
+bool mailbox_wait(const unsigned long long* host_slot, uint32_t seq, uint32_t* value)
+{
+    const volatile unsigned long long* p = host_slot;
+    for (long spin = 0; spin < 400000000L; spin++) {
+        const unsigned long long v = *p;
+        if ((uint32_t)(v >> 32) == seq) { *value = (uint32_t)v; return true; }
+        __builtin_ia32_pause();
+        if ((spin & 0xFFFFF) == 0xFFFFF && hipPeekAtLastError() != hipSuccess) return false;
+    }
+    return false;
+}
+
 __global__ void __launch_bounds__(256) export_geom_kernel(int P, const float* __restrict__ splat, float* means2D, float* depths,
                                                           float* conic_opacity, float* rgb)
 {
@@ -123,11 +169,19 @@ int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float*
     a.tiles_touched = (uint32_t*)(g + L.tiles_touched); a.block_sums = (uint32_t*)(g + L.block_sums);
     { StageTimer t(GSR_STAGE_PREPROCESS, s); gsr_launch_preprocess(a, s); }
     const int nb = (P + 255) / 256;
-    { StageTimer t(GSR_STAGE_SCAN, s); gsr_launch_scan_blocks(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), s); }
+    unsigned long long *mail_host = nullptr, *mail_dev = nullptr;
+    uint32_t seq = 0;
+    const bool mail = gsr_variant("MAILBOX", 1) && mailbox_acquire(&mail_host, &mail_dev, &seq);
+    {
+        StageTimer t(GSR_STAGE_SCAN, s);
+        gsr_launch_scan_blocks(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), mail ? mail_dev : nullptr, seq, s);
+    }
     uint32_t total = 0;
-    hipError_t e = hipMemcpyAsync(&total, g + L.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return fail(-100, "forward_geometry: %s", hipGetErrorString(e));
+    if (!mail || !mailbox_wait(mail_host, seq, &total)) {
+        hipError_t e = hipMemcpyAsync(&total, g + L.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(-100, "forward_geometry: %s", hipGetErrorString(e));
+    }
     *num_rendered_host = (int64_t)total;
     return check_hip("forward_geometry");
 }
@@ -196,6 +250,23 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
                                   (uint32_t*)(im + I.n_contrib), out_color, flags, s);
     }
     return check_hip("forward_render");
+}
+
+int gsr_forward(int P, int D, int M, const float* background, const float* means3D, const float* scales, float scale_modifier,
+                const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H,
+                float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* geom_buffer, size_t geom_bytes,
+                void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes, float* out_color,
+                int64_t* num_rendered_host, void* stream)
+{
+    const int rc = gsr_forward_geometry(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+                                        colors_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered, radii,
+                                        geom_buffer, geom_bytes, num_rendered_host, stream);
+    if (rc != 0) return rc;
+    const int64_t R = *num_rendered_host;
+    if (R > 0 && gsr_bin_layout((long)R, P, W, H).bytes > binning_bytes) return 1;  // caller re-allocates and calls gsr_forward_render
+    return gsr_forward_render(P, R, W, H, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer,
+                              image_bytes, out_color, stream);
 }
 
 int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* means3D,

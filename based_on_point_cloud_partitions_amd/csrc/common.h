@@ -120,7 +120,8 @@ struct PreprocessArgs {
     float* splat; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched; uint32_t* block_sums;
 };
 void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s);
-void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, hipStream_t s);
+void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
+                            unsigned long long* mailbox, uint32_t seq, hipStream_t s);
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
                      uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s);
 // returns 0 if the sorted pairs end in (ka,va), 1 if in (kb,vb)

@@ -186,8 +186,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
 }
 
 // Exclusive scan of the per-workgroup sums (single workgroup, 1024 threads, chunked with a carry).
+// `mailbox` (optional) is a word of host-mapped pinned memory: the total is published there, tagged with `seq`, so the
+// host can pick it up by polling instead of queueing a copy and synchronising the stream.
 __global__ void __launch_bounds__(1024) scan_blocks_kernel(int n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                            uint32_t* __restrict__ total)
+                                                            uint32_t* __restrict__ total, unsigned long long* mailbox, uint32_t seq)
 {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
@@ -213,7 +215,11 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(int n, const uint32_t
         if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry_s;
+    if (threadIdx.x == 0) {
+        *total = carry_s;
+        if (mailbox)
+            __hip_atomic_store(mailbox, ((unsigned long long)seq << 32) | carry_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Key emission.  Workgroup-local exclusive scan of tiles_touched + the scanned workgroup offset gives
@@ -303,9 +309,10 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, focal_x, focal_y, gx, gy);
 }
 
-void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, hipStream_t s)
+void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
+                            unsigned long long* mailbox, uint32_t seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total, mailbox, seq);
 }
 
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,

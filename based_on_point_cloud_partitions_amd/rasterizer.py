@@ -16,6 +16,10 @@ from . import _lib
 
 NUM_CHANNELS = 3  # cuda_rasterizer/config.h:14
 
+# Largest num_rendered seen per (device, P, W, H): sizes the binning buffer BEFORE the forward so that both phases run
+# in one native call (gsr_forward); a too-small guess only costs a second call.
+_R_SEEN = {}
+
 
 def _ptr(t):
     """Device pointer or NULL for an absent (empty) optional tensor (rasterize_points.cu:94-111 convention)."""
@@ -56,8 +60,11 @@ def rasterize_gaussians_forward(background, means3D, colors, opacity, scales, ro
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
     with torch.cuda.device(dev):
-        out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        # P > 0: every pixel and every radius is written by the kernels; P == 0: nothing runs and both stay zero
+        # (torch::full(0.0) in the reference, rasterize_points.cu:68-69)
+        alloc = torch.empty if P != 0 else torch.zeros
+        out_color = alloc((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        radii = alloc((P,), dtype=torch.int32, device=dev)
         byte = dict(dtype=torch.uint8, device=dev)
         geomBuffer = torch.empty(0, **byte)
         binningBuffer = torch.empty(0, **byte)
@@ -75,17 +82,24 @@ def rasterize_gaussians_forward(background, means3D, colors, opacity, scales, ro
                 raise _lib.GsrError("opacities must have one value per Gaussian")
             geomBuffer = torch.empty(lib.gsr_geometry_bytes(P), **byte)
             imgBuffer = torch.empty(lib.gsr_image_bytes(W, H), **byte)
+            key = (dev.index, P, W, H)
+            guess = _R_SEEN.get(key, 0)
+            binningBuffer = torch.empty(lib.gsr_binning_bytes(guess + guess // 4, P, W, H) if guess > 0 else 0, **byte)
             R = ctypes.c_int64(0)
             s = _stream(dev)
-            _lib.check(lib.gsr_forward_geometry(
-                P, int(degree), int(M), _ptr(means3D_c), _ptr(scales_c), float(scale_modifier), _ptr(rot_c), _ptr(opacity_c),
-                _ptr(sh_c), _ptr(cov_c), _ptr(colors_c), _ptr(vm), _ptr(pm), _ptr(cp), W, H, float(tan_fovx), float(tan_fovy),
-                int(bool(prefiltered)), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), ctypes.byref(R), s), "gsr_forward_geometry")
+            rc = _lib.check(lib.gsr_forward(
+                P, int(degree), int(M), _ptr(bg), _ptr(means3D_c), _ptr(scales_c), float(scale_modifier), _ptr(rot_c),
+                _ptr(opacity_c), _ptr(sh_c), _ptr(cov_c), _ptr(colors_c), _ptr(vm), _ptr(pm), _ptr(cp), W, H, float(tan_fovx),
+                float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                binningBuffer.numel(), _ptr(imgBuffer), imgBuffer.numel(), _ptr(out_color), ctypes.byref(R), s), "gsr_forward")
             rendered = int(R.value)
-            binningBuffer = torch.empty(lib.gsr_binning_bytes(rendered, P, W, H) if rendered > 0 else 0, **byte)
-            _lib.check(lib.gsr_forward_render(
-                P, rendered, W, H, _ptr(bg), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer), binningBuffer.numel(),
-                _ptr(imgBuffer), imgBuffer.numel(), _ptr(out_color), s), "gsr_forward_render")
+            if rc == 1:  # estimate too small (or first call): phase 2 with an exactly sized buffer
+                binningBuffer = torch.empty(lib.gsr_binning_bytes(rendered, P, W, H), **byte)
+                _lib.check(lib.gsr_forward_render(
+                    P, rendered, W, H, _ptr(bg), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer), binningBuffer.numel(),
+                    _ptr(imgBuffer), imgBuffer.numel(), _ptr(out_color), s), "gsr_forward_render")
+            if rendered > guess:
+                _R_SEEN[key] = rendered
             if debug:
                 torch.cuda.synchronize(dev)  # CHECK_CUDA(..., debug), auxiliary.h:166-173
     return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer

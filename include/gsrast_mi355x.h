@@ -44,7 +44,7 @@ size_t gsr_backward_scratch_bytes(int64_t R);
 
 /* Phase 1 of CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:198-285): frustum cull, covariance
  * projection, SH colour, tiles_touched and its prefix sum.  Writes radii[P] and *num_rendered_host (host
- * pointer; the call synchronises `stream` once to read it, like the reference's cudaMemcpy at :281). */
+ * pointer; the call waits for the prefix sum to read it, like the reference's cudaMemcpy at :281). */
 int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                          const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
                          const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
@@ -56,6 +56,17 @@ int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float*
 int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, void* geom_buffer, size_t geom_bytes,
                        void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes,
                        float* out_color, void* stream);
+
+/* Both phases in one call, for callers that bring a binning buffer sized from an estimate (e.g. the previous step's R):
+ * runs phase 1, reads R, and continues with phase 2 without returning to the caller if `binning_bytes` suffices.
+ * Returns 0 when the image is complete, 1 when the binning buffer is too small (then *num_rendered_host is valid, phase 1
+ * is done, and the caller allocates gsr_binning_bytes(R, P, W, H) bytes and calls gsr_forward_render), negative on error. */
+int gsr_forward(int P, int D, int M, const float* background, const float* means3D, const float* scales, float scale_modifier,
+                const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H,
+                float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* geom_buffer, size_t geom_bytes,
+                void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes, float* out_color,
+                int64_t* num_rendered_host, void* stream);
 
 /* CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:340-434) + the zero-initialised outputs of
  * RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-159): every output element is written.
