@@ -130,6 +130,58 @@ def test_many_equal_depths_tie_break_by_index():
     assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
 
 
+def test_more_than_16384_tiles_multi_chunk_binning():
+    # 132 x 132 = 17,424 tiles: the tile histogram no longer fits one LDS pass (TCHUNK = 16384 in binning.hip)
+    st, _ = _fwd_bwd(P=60_000, W=2100, H=2100, focal=1500.0, seed=19, scale_lo=0.004, scale_hi=0.03)
+    assert st["ranges"].shape[0] > 16384 and (st["ranges"][16384:, 1] > st["ranges"][16384:, 0]).any()
+
+
+def test_config4_2M_gaussians_with_densify_prune_stress():
+    """BASELINE.json configs[3]: 2M-Gaussian whole scene at 1080p on one GPU; scripted clone (+5 %) / prune (-5 %) between
+    renders re-sizes every state buffer.  Full oracle parity on the first and the last state."""
+    import torch
+
+    from based_on_point_cloud_partitions_amd import GaussianRasterizer
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    P0, W, H = 2_000_000, 1920, 1080
+    g = syn.make_gaussians(P0, seed=0, box_min=(-8.0, -8.0, -1.0), box_max=(8.0, 8.0, 1.0))
+    cams = syn.ring_cameras(16, W, H, 1200.0)
+    dev = "cuda"
+    cur = [t.to(dev) for t in g]
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    dL = torch.randn(3, H, W, generator=gen).to(dev)
+
+    def check(parts, cam):
+        gg = syn.SyntheticGaussians(*[t.cpu() for t in parts])
+        st = oracle_forward(gg, cam)
+        ctx = hip_forward_raw(gg, cam)
+        assert_forward_bit_exact(ctx, st)
+        assert_grads_close(hip_backward_raw(ctx, dL.cpu().numpy()), oracle.backward(st, dL.cpu().numpy()))
+        return st["num_rendered"]
+
+    R0 = check(cur, cams[0])
+    assert R0 > 5_000_000
+    for it in range(6):
+        xyz, scales, rots, opac, shs = [t.clone().requires_grad_(True) for t in cur]
+        rast = GaussianRasterizer(hip_settings(cams[(it + 1) % 16], (0.0, 0.0, 0.0), 3, device=dev))
+        img, radii = rast(means3D=xyz, means2D=torch.zeros_like(xyz, requires_grad=True), opacities=opac, shs=shs, scales=scales,
+                          rotations=rots)
+        img.backward(dL)
+        assert torch.isfinite(img).all() and torch.isfinite(xyz.grad).all() and radii.shape[0] == xyz.shape[0]
+        # densify: clone 5 % of the points with jitter; prune: drop the 5 % with the lowest opacity
+        n = xyz.shape[0]
+        pick = torch.randperm(n, generator=gen)[: n // 20].to(dev)
+        jitter = 0.01 * torch.randn(pick.numel(), 3, generator=gen).to(dev)
+        new = [torch.cat((cur[0], cur[0][pick] + jitter))] + [torch.cat((t, t[pick])) for t in cur[1:]]
+        keep = torch.argsort(new[3][:, 0], descending=True)[: new[0].shape[0] - n // 20]
+        keep, _ = torch.sort(keep)
+        cur = [t[keep].contiguous() for t in new]
+    assert cur[0].shape[0] == P0
+    check(cur, cams[7])
+    assert torch.cuda.max_memory_allocated() < 40e9  # a 2M scene is far from the 288 GB of one MI355X
+
+
 def test_precomputed_colors_and_covariance():
     _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=21, colors=True, cov=True, bg=(0.5, 0.5, 0.5))
     _fwd_bwd(P=3000, W=128, H=128, focal=90.0, seed=22, colors=True, cov=False)
