@@ -40,6 +40,9 @@ PROTOTYPES = {
                              c_void_p, c_size, c_void_p, c_size, c_void_p, c_size, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_loss_scratch_bytes": (c_size, [c_int, c_int, c_int]),
+    "gsr_loss_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p]),
+    "gsr_loss_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p, c_void_p]),
     "gsr_knn_scratch_bytes": (c_size, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),

@@ -90,6 +90,17 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 size_t gsr_knn_scratch_bytes(int P);
 int gsr_knn_mean_dist2(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Loss block of the training step: loss = (1 - lambda) * L1(img1, img2) + lambda * (1 - SSIM(img1, img2)),
+ * the reference's utils/loss_utils.py:17-18,23-63 combined as in train.py:116-117 (11-tap Gaussian window, sigma 1.5, zero
+ * padding, mean over C*H*W).  Images are [C][H][W] float32 on the device.  gsr_loss_forward writes out3 = {loss, L1, SSIM}
+ * (device) and keeps the per-pixel partial derivatives in `scratch` (gsr_loss_scratch_bytes); gsr_loss_backward turns them
+ * into dL/dimg1 scaled by *grad_loss (device scalar, NULL = 1), i.e. the dL/dcolor the rasterizer's backward consumes. */
+size_t gsr_loss_scratch_bytes(int C, int H, int W);
+int gsr_loss_forward(int C, int H, int W, const float* img1, const float* img2, float lambda_dssim, void* scratch,
+                     size_t scratch_bytes, float* out3, void* stream);
+int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2, float lambda_dssim, const void* scratch,
+                      size_t scratch_bytes, const float* grad_loss, float* dL_dimg1, void* stream);
+
 /* Test/inspection hook: copies the intermediates held in the opaque buffers into plain arrays (any output may
  * be NULL).  means2D[P][2], depths[P], conic_opacity[P][4], rgb[P][3], cov3D[P][6], clamped[P][3],
  * tiles_touched[P], point_offsets[P], keys_sorted[R], point_list[R], ranges[T][2], final_T[H*W], n_contrib[H*W]. */

@@ -886,3 +886,90 @@ void orc_knn_bruteforce(int P, const float* pts, float* meanDists)
         meanDists[i] = (best[0] + best[1] + best[2]) / 3.0f;
     }
 }
+
+/* ========================================================================
+ * Loss block of the training step: utils/loss_utils.py of the reference --
+ * l1_loss (:17-18), gaussian/create_window (:23-31), ssim/_ssim (:33-63), combined as in train.py:116-117
+ *     loss = (1 - lambda) * L1(img1, img2) + lambda * (1 - ssim(img1, img2)).
+ * PINNED: the reference's loss_utils.py is importable; tests/golden/ref_loss.npz holds its outputs and autograd
+ * gradients, and this restatement is checked against them.
+ * The window is the reference's: 1-D Gaussian (sigma 1.5, 11 taps) normalised in float32, 2-D = outer product in
+ * float32, zero padding (F.conv2d(padding=5, groups=C)).
+ * ======================================================================== */
+static const float SSIM_W1[11] = {0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb18p-5f, 0x1.bff0fep-4f, 0x1.b43c3ep-3f, 0x1.10656p-2f,
+                                  0x1.b43c3ep-3f,  0x1.bff0fep-4f, 0x1.26eb18p-5f, 0x1.f1fe02p-8f, 0x1.0d956cp-10f};
+
+/* out[0] = loss, out[1] = L1, out[2] = ssim.  dL_dimg1 (optional) = d loss / d img1.  Images are [C][H][W]. */
+void orc_l1_ssim_loss(int C, int H, int W, const float* img1, const float* img2, float lambda, float* out, float* dL_dimg1)
+{
+    const size_t N = (size_t)C * H * W;
+    float w2[11][11];
+    for (int i = 0; i < 11; i++)
+        for (int j = 0; j < 11; j++) w2[i][j] = SSIM_W1[i] * SSIM_W1[j]; /* _1D_window.mm(_1D_window.t()) */
+    const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
+    float* dmu1 = (float*)calloc(N, sizeof(float));
+    float* de11 = (float*)calloc(N, sizeof(float));
+    float* de12 = (float*)calloc(N, sizeof(float));
+    double ssim_sum = 0.0, l1_sum = 0.0;
+#pragma omp parallel for collapse(2) schedule(static) reduction(+ : ssim_sum, l1_sum)
+    for (int c = 0; c < C; c++)
+        for (int y = 0; y < H; y++) {
+            const float* a = img1 + (size_t)c * H * W;
+            const float* b = img2 + (size_t)c * H * W;
+            for (int x = 0; x < W; x++) {
+                float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+                for (int i = 0; i < 11; i++) {
+                    const int yy = y + i - 5;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int j = 0; j < 11; j++) {
+                        const int xx = x + j - 5;
+                        if (xx < 0 || xx >= W) continue;
+                        const float p = a[(size_t)yy * W + xx], q = b[(size_t)yy * W + xx], w = w2[i][j];
+                        mu1 += w * p; mu2 += w * q; e11 += w * (p * p); e22 += w * (q * q); e12 += w * (p * q);
+                    }
+                }
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+                const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu1_mu2;
+                const float A = 2 * mu1_mu2 + C1, B = 2 * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
+                const float m = (A * B) / (Cc * D);
+                ssim_sum += m;
+                const size_t id = (size_t)c * H * W + (size_t)y * W + x;
+                l1_sum += fabsf(a[(size_t)y * W + x] - b[(size_t)y * W + x]);
+                /* partial derivatives of the map value w.r.t. the five window sums (e11, e12, mu1 treated as inputs) */
+                const float inv = 1.0f / (Cc * D);
+                dmu1[id] = (2 * mu2 * B - 2 * mu2 * A) * inv - m * (2 * mu1 * D - 2 * mu1 * Cc) * inv;
+                de11[id] = -m / D;
+                de12[id] = 2 * A * inv;
+            }
+        }
+    const float l1 = (float)(l1_sum / (double)N), ssim = (float)(ssim_sum / (double)N);
+    out[0] = (1.0f - lambda) * l1 + lambda * (1.0f - ssim);
+    out[1] = l1;
+    out[2] = ssim;
+    if (dL_dimg1) {
+        const float gs = -lambda / (float)N, gl = (1.0f - lambda) / (float)N;
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int c = 0; c < C; c++)
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) {
+                    const size_t base = (size_t)c * H * W;
+                    float s_mu = 0, s_11 = 0, s_12 = 0;
+                    for (int i = 0; i < 11; i++) {
+                        const int yy = y + i - 5;
+                        if (yy < 0 || yy >= H) continue;
+                        for (int j = 0; j < 11; j++) {
+                            const int xx = x + j - 5;
+                            if (xx < 0 || xx >= W) continue;
+                            const size_t id = base + (size_t)yy * W + xx;
+                            const float w = w2[i][j];
+                            s_mu += w * dmu1[id]; s_11 += w * de11[id]; s_12 += w * de12[id];
+                        }
+                    }
+                    const size_t id = base + (size_t)y * W + x;
+                    const float d = img1[id] - img2[id];
+                    const float sgn = d > 0 ? 1.0f : (d < 0 ? -1.0f : 0.0f);
+                    dL_dimg1[id] = gs * (s_mu + 2 * img1[id] * s_11 + img2[id] * s_12) + gl * sgn;
+                }
+    }
+    free(dmu1); free(de11); free(de12);
+}

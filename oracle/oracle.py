@@ -181,3 +181,15 @@ def knn_mean_dist2(points, bruteforce=False):
         fn = L.orc_knn_bruteforce if bruteforce else L.orc_knn_mean_dist2
         fn(ctypes.c_int(P), _p(pts, _f), _p(out, _f))
     return out
+
+
+def l1_ssim_loss(img1, img2, lambda_dssim=0.2, grad=True):
+    """utils/loss_utils.py (l1_loss, ssim) combined as train.py:116-117. Returns (loss, l1, ssim, dloss/dimg1 or None)."""
+    L = lib()
+    a = _f32(img1); b = _f32(img2)
+    C, H, W = a.shape
+    out = np.zeros(3, np.float32)
+    g = np.zeros_like(a) if grad else None
+    L.orc_l1_ssim_loss(ctypes.c_int(C), ctypes.c_int(H), ctypes.c_int(W), _p(a, _f), _p(b, _f), ctypes.c_float(lambda_dssim),
+                       _p(out, _f), _p(g, _f))
+    return float(out[0]), float(out[1]), float(out[2]), g

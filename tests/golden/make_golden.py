@@ -75,6 +75,28 @@ def ref_cameras():
     np.savez_compressed(os.path.join(HERE, "ref_cameras.npz"), **out)
 
 
+def ref_loss():
+    """Outputs of the reference's own utils/loss_utils.py (l1_loss, ssim) and autograd gradients, train.py:116-117."""
+    lu = _load("ref_loss_utils", "utils/loss_utils.py")
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    k = 0
+    for (C, H, W) in [(3, 37, 53), (3, 64, 48), (1, 20, 20)]:
+        gt = torch.rand(C, H, W, generator=g)
+        img = (gt + 0.15 * torch.randn(C, H, W, generator=g)).clamp(0, 1.2).requires_grad_(True)
+        lam = 0.2
+        Ll1 = lu.l1_loss(img, gt)
+        s = lu.ssim(img, gt)
+        loss = (1.0 - lam) * Ll1 + lam * (1.0 - s)
+        loss.backward()
+        out[f"img{k}"] = img.detach().numpy(); out[f"gt{k}"] = gt.numpy()
+        out[f"res{k}"] = np.array([loss.item(), Ll1.item(), s.item(), lam], dtype=np.float64)
+        out[f"grad{k}"] = img.grad.numpy()
+        k += 1
+    out["n"] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, "ref_loss.npz"), **out)
+
+
 def _h(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
@@ -115,6 +137,7 @@ def oracle_snapshot():
 if __name__ == "__main__":
     ref_sh()
     ref_cameras()
+    ref_loss()
     oracle_snapshot()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
