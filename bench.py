@@ -76,6 +76,53 @@ def cpu_baseline(cfg, g, cam, dL):
                       f"forward {t1 - t0:.2f} s + backward {t2 - t1:.2f} s, OpenMP over Gaussians/tiles"}
 
 
+def torch_l1_ssim(img, gt, lam):
+    """Stock-PyTorch evaluation of utils/loss_utils.py + train.py:116-117 (what the reference runs on the GPU), for timing."""
+    import torch.nn.functional as F
+    from math import exp
+
+    g1 = torch.tensor([exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)], device=img.device)
+    g1 = (g1 / g1.sum()).unsqueeze(1)
+    C = img.size(-3)
+    window = g1.mm(g1.t()).float().unsqueeze(0).unsqueeze(0).expand(C, 1, 11, 11).contiguous()
+    mu1 = F.conv2d(img, window, padding=5, groups=C)
+    mu2 = F.conv2d(gt, window, padding=5, groups=C)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img * img, window, padding=5, groups=C) - mu1_sq
+    sigma2_sq = F.conv2d(gt * gt, window, padding=5, groups=C) - mu2_sq
+    sigma12 = F.conv2d(img * gt, window, padding=5, groups=C) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return (1.0 - lam) * torch.abs(img - gt).mean() + lam * (1.0 - ssim_map.mean())
+
+
+def full_step_timing(args, rasterizers, params, tensors, H, W, dev):
+    """Context figure (not the headline): render + loss + backward per step, fused HIP loss vs stock torch loss."""
+    from based_on_point_cloud_partitions_amd import loss as hip_loss
+
+    xyz, scales, rots, opac, shs = tensors
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+    res = {}
+    for name, fn in (("hip_fused_loss", lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)), ("torch_loss", lambda im: torch_l1_ssim(im, gt, 0.2))):
+        def one(i):
+            r = rasterizers[i % len(rasterizers)]
+            screenspace = torch.zeros_like(xyz, requires_grad=True)
+            image, _ = r(means3D=xyz, means2D=screenspace, opacities=opac, shs=shs, scales=scales, rotations=rots)
+            fn(image).backward()
+            for p in params:
+                p.grad = None
+        for i in range(4):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one(4 + i)
+        torch.cuda.synchronize()
+        res[name + "_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
+    res["note"] = "render + (1-0.2)*L1 + 0.2*(1-SSIM) + backward on the same workload; context only, not the headline metric"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +131,8 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(syn.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true", help="time the region without per-stage HIP events")
+    ap.add_argument("--full-step", action="store_true",
+                    help="also time render + L1/SSIM loss + backward (train.py:107-118), fused HIP loss vs stock torch ops")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +226,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    full = None
+    if args.full_step:
+        full = full_step_timing(args, rasterizers, params, (xyz, scales, rots, opac, shs), H, W, dev)
+
     if rank == 0:
         used = [stats[(args.warmup + i) % len(stats)] for i in range(args.steps)]
         V = float(np.mean([u["V"] for u in used]))
@@ -231,6 +284,8 @@ def main():
                               "frac": round(step_bytes / 1e9 / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 4)},
             "roofline_kernels": kernels,
         }
+        if full is not None:
+            out["full_step"] = full
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, g, cams[0], dL_cpu.numpy())
         print(json.dumps(out), flush=True)
