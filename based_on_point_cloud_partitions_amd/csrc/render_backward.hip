@@ -224,28 +224,30 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             const float alpha = fminf(0.99f, b.y * G);
             contrib = contrib && alpha >= 1.0f / 255.0f;
             if (__ballot(contrib) == 0ull) continue;  // wave-uniform
-            // From here all 64 lanes run the same straight-line code; lanes that do not contribute are neutralised by
-            // selecting w = aT = 0 and by not committing their state.
+            // From here all 64 lanes run the same straight-line code.  A lane that does not contribute is given alpha = G = 0:
+            // then T/(1-0) = T, its gradient terms vanish, and the colour recurrence (backward.cu:515) folds the pending
+            // (last_alpha, last_color) into accum exactly once -- the same value the next real contributor would have
+            // computed -- so no per-variable select is needed.
+            const float Ge = contrib ? G : 0.f;
+            const float ae = contrib ? alpha : 0.f;
             const float4 c = s_c[j];
-            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-            const float Tn = T * inv;  // T / (1 - alpha), backward.cu:502
+            const float inv = __builtin_amdgcn_rcpf(1.f - ae);
+            T = T * inv;  // T / (1 - alpha), backward.cu:502
             const float oma = 1.f - last_alpha;
-            const float ac0 = __builtin_fmaf(last_alpha, lc0, oma * accum0);
-            const float ac1 = __builtin_fmaf(last_alpha, lc1, oma * accum1);
-            const float ac2 = __builtin_fmaf(last_alpha, lc2, oma * accum2);
-            float dL_dalpha = (c.x - ac0) * dL0;
-            dL_dalpha = __builtin_fmaf(c.y - ac1, dL1, dL_dalpha);
-            dL_dalpha = __builtin_fmaf(c.z - ac2, dL2, dL_dalpha);
-            dL_dalpha *= Tn;
+            accum0 = __builtin_fmaf(last_alpha, lc0, oma * accum0);
+            accum1 = __builtin_fmaf(last_alpha, lc1, oma * accum1);
+            accum2 = __builtin_fmaf(last_alpha, lc2, oma * accum2);
+            lc0 = c.x; lc1 = c.y; lc2 = c.z;
+            last_alpha = ae;
+            float dL_dalpha = (c.x - accum0) * dL0;
+            dL_dalpha = __builtin_fmaf(c.y - accum1, dL1, dL_dalpha);
+            dL_dalpha = __builtin_fmaf(c.z - accum2, dL2, dL_dalpha);
+            dL_dalpha *= T;
             dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
-            const float w = contrib ? G * dL_dalpha : 0.f;
-            const float aT = contrib ? alpha * Tn : 0.f;
+            const float w = Ge * dL_dalpha;
+            const float aT = ae * T;
             const float wdx = w * dx, wdy = w * dy;
             float v0 = w, v1 = wdx, v2 = wdy, v3 = wdx * dx, v4 = wdx * dy, v5 = wdy * dy, v6 = aT * dL0, v7 = aT * dL1, v8 = aT * dL2;
-            T = contrib ? Tn : T;
-            accum0 = contrib ? ac0 : accum0; accum1 = contrib ? ac1 : accum1; accum2 = contrib ? ac2 : accum2;
-            lc0 = contrib ? c.x : lc0; lc1 = contrib ? c.y : lc1; lc2 = contrib ? c.z : lc2;
-            last_alpha = contrib ? alpha : last_alpha;
             if constexpr (RS) {
                 const float tot = wave_sum9_scatter(v0, v1, v2, v3, v4, v5, v6, v7, v8, M0, M1, M2, M8);
                 if (lane < 9) my_acc[j * NV + my_slot] = tot;
