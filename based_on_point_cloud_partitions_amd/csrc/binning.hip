@@ -106,10 +106,13 @@ __global__ void __launch_bounds__(1024) tile_starts_kernel(int T, const uint32_t
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < T; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < T ? totals[i] : 0u;
-        uint32_t incl = v;
+    constexpr int EPT = 8;  // tiles per thread and iteration: 1080p (8,160 tiles) is a single iteration
+    for (int base = 0; base < T; base += 1024 * EPT) {
+        const int i0 = base + threadIdx.x * EPT;
+        uint32_t v[EPT], tsum = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) { v[e] = i0 + e < T ? totals[i0 + e] : 0u; tsum += v[e]; }
+        uint32_t incl = tsum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t u = __shfl_up(incl, off, 64);
@@ -120,11 +123,16 @@ __global__ void __launch_bounds__(1024) tile_starts_kernel(int T, const uint32_t
         uint32_t wbase = 0;
         for (int w = 0; w < wave; w++) wbase += wtot[w];
         const uint32_t carry = carry_s;
-        if (i < T) {
-            const uint32_t s = carry + wbase + incl - v;
-            starts[i] = s;
-            ranges[2 * i] = v ? s : 0u;          // identifyTileRanges leaves empty tiles at (0,0) after the memset
-            ranges[2 * i + 1] = v ? s + v : 0u;
+        uint32_t s = carry + wbase + incl - tsum;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = i0 + e;
+            if (i < T) {
+                starts[i] = s;
+                ranges[2 * i] = v[e] ? s : 0u;          // identifyTileRanges leaves empty tiles at (0,0) after the memset
+                ranges[2 * i + 1] = v[e] ? s + v[e] : 0u;
+            }
+            s += v[e];
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + wbase + incl;

@@ -36,43 +36,6 @@ struct GaussBackwardPtrs {
     float scale_modifier, tan_fovx, tan_fovy;
 };
 
-// Moves the workgroup's [rows][3M] tile between global memory and LDS (row stride `stride` floats in LDS).
-__device__ __forceinline__ void sh_tile_load(const float* __restrict__ g, float* __restrict__ s, int rows, int n3, int stride)
-{
-    const int count = rows * n3;
-    if ((n3 & 3) == 0) {
-        const float4* g4 = reinterpret_cast<const float4*>(g);
-        for (int f = threadIdx.x; f < (count >> 2); f += 256) {
-            const float4 v = g4[f];
-            const int e = f << 2, r = e / n3, c = e - r * n3;
-            float* d = s + r * stride + c;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-    } else {
-        for (int e = threadIdx.x; e < count; e += 256) {
-            const int r = e / n3, c = e - r * n3;
-            s[r * stride + c] = g[e];
-        }
-    }
-}
-__device__ __forceinline__ void sh_tile_store(float* __restrict__ g, const float* __restrict__ s, int rows, int n3, int stride)
-{
-    const int count = rows * n3;
-    if ((n3 & 3) == 0) {
-        float4* g4 = reinterpret_cast<float4*>(g);
-        for (int f = threadIdx.x; f < (count >> 2); f += 256) {
-            const int e = f << 2, r = e / n3, c = e - r * n3;
-            const float* d = s + r * stride + c;
-            g4[f] = make_float4(d[0], d[1], d[2], d[3]);
-        }
-    } else {
-        for (int e = threadIdx.x; e < count; e += 256) {
-            const int r = e / n3, c = e - r * n3;
-            g[e] = s[r * stride + c];
-        }
-    }
-}
-
 __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
 {
     extern __shared__ float s_tile[];  // [256][3M + 1]

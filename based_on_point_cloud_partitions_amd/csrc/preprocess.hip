@@ -69,7 +69,15 @@ struct PreprocessPtrs {
 
 __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float focal_x, float focal_y, int gx, int gy)
 {
+    // SH rows are 192 B per Gaussian: the workgroup's 256 rows come in through LDS with coalesced 16-byte loads and are read
+    // per thread with an odd row stride (see gaussian_backward.hip)
+    extern __shared__ float s_sh[];
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n3 = 3 * a.M, sh_stride = n3 + 1;
+    if (a.shs) {
+        sh_tile_load(a.shs + (size_t)blockIdx.x * 256 * n3, s_sh, min(256, a.P - (int)blockIdx.x * 256), n3, sh_stride);
+        __syncthreads();
+    }
     uint32_t touched = 0;
     if (idx < a.P) {
         float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;  // culled: radius 0
@@ -158,7 +166,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
                         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                         F3 dir{dx / len, dy / len, dz / len};
                         bool cl[3];
-                        const F3 c = sh_to_rgb(a.D, a.shs + (size_t)idx * a.M * 3, dir, cl);
+                        const F3 c = sh_to_rgb(a.D, s_sh + threadIdx.x * sh_stride, dir, cl);
                         cr = c.x; cg = c.y; cb = c.z;
                         a.clamped[3 * idx] = cl[0]; a.clamped[3 * idx + 1] = cl[1]; a.clamped[3 * idx + 2] = cl[2];
                     }
@@ -306,7 +314,8 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     p.radii = a.radii; p.splat = a.splat; p.cov3D = a.cov3D; p.clamped = a.clamped; p.tiles_touched = a.tiles_touched;
     p.block_sums = a.block_sums;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, focal_x, focal_y, gx, gy);
+    const size_t lds = a.shs ? (size_t)256 * (3 * a.M + 1) * 4 : 0;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), lds, s, p, focal_x, focal_y, gx, gy);
 }
 
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
