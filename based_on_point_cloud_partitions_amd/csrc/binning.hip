@@ -222,26 +222,26 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr a, uint32_t n, uint32_t N
 // tile to the bitonic path, so the worst case stays n log^2 n.
 constexpr int BUCKET_CAP = 2048;
 constexpr int BUCKET_LIMIT = 16;
-constexpr int BUCKET_EPT = BUCKET_CAP / 256;  // entries / buckets per thread
+struct BucketSortLds {
+    unsigned long long keys[BUCKET_CAP];
+    uint32_t cnt[BUCKET_CAP + 1];
+    uint32_t red[8];
+    uint32_t wsum[4];
+    int overflow;
+};
 
-__global__ void __launch_bounds__(256) tile_sort_small_kernel(const uint32_t* __restrict__ ranges,
-                                                              const unsigned long long* __restrict__ bins,
-                                                              uint32_t* __restrict__ point_list,
-                                                              unsigned long long* __restrict__ keys_sorted)
+// BUCKET_EPT = entries (and buckets) per thread: 2, 4 or 8 for lists of up to 512, 1024, 2048 entries
+template <int BUCKET_EPT>
+__device__ __forceinline__ void bucket_sort_tile(BucketSortLds& L, uint32_t tile, uint32_t r0, uint32_t n, uint32_t N,
+                                                 const unsigned long long* __restrict__ bins, uint32_t* __restrict__ point_list,
+                                                 unsigned long long* __restrict__ keys_sorted)
 {
-    __shared__ unsigned long long s_keys[BUCKET_CAP];
-    __shared__ uint32_t s_cnt[BUCKET_CAP + 1];
-    __shared__ uint32_t s_red[8];
-    __shared__ uint32_t s_wsum[4];
-    __shared__ int s_overflow;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
-    const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
-    const uint32_t n = r1 - r0;
-    if (n == 0 || n > BUCKET_CAP) return;  // empty, or handled by tile_sort_large_kernel
+    unsigned long long* s_keys = L.keys;
+    uint32_t* s_cnt = L.cnt;
+    uint32_t* s_red = L.red;
+    uint32_t* s_wsum = L.wsum;
+    int& s_overflow = L.overflow;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t N = 1;
-    while (N < n) N <<= 1;
     const unsigned long long* seg = bins + r0;
     unsigned long long key[BUCKET_EPT];
     uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
@@ -338,6 +338,24 @@ __global__ void __launch_bounds__(256) tile_sort_small_kernel(const uint32_t* __
         point_list[r0 + i] = (uint32_t)k;
         if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
     }
+}
+
+__global__ void __launch_bounds__(256) tile_sort_small_kernel(const uint32_t* __restrict__ ranges,
+                                                              const unsigned long long* __restrict__ bins,
+                                                              uint32_t* __restrict__ point_list,
+                                                              unsigned long long* __restrict__ keys_sorted)
+{
+    __shared__ BucketSortLds L;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+    const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
+    const uint32_t n = r1 - r0;
+    if (n == 0 || n > BUCKET_CAP) return;  // empty, or handled by tile_sort_large_kernel
+    uint32_t N = 1;
+    while (N < n) N <<= 1;
+    if (N <= 512) bucket_sort_tile<2>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+    else if (N <= 1024) bucket_sort_tile<4>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+    else bucket_sort_tile<8>(L, tile, r0, n, N, bins, point_list, keys_sorted);
 }
 
 // (5b) one workgroup per tile, lists longer than BUCKET_CAP: bitonic network in LDS (<= SORT_CAP) or in place in HBM.
