@@ -40,17 +40,20 @@ __device__ __forceinline__ SliceRect load_rect(const float* __restrict__ splat, 
     return r;
 }
 
-// (1) per-slice tile histogram.  grid = nslices, block = 256, dynamic LDS = min(T, TCHUNK) * 4 bytes.
-__global__ void __launch_bounds__(256) tile_count_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
+// (1) per-slice tile histogram.  grid = nslices, block = SLICE_THREADS, dynamic LDS = min(T, TCHUNK) * 4 bytes.
+// 1024 threads per workgroup: with ~500 slices there are only ~2 workgroups per CU, and each instance is a dependent
+// LDS-atomic -> global-store chain, so the latency is hidden by waves, not by work per thread.
+constexpr int SLICE_THREADS = 1024;
+__global__ void __launch_bounds__(SLICE_THREADS) tile_count_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
                                                          uint32_t* __restrict__ table)
 {
     extern __shared__ uint32_t s_hist[];
     const int first = blockIdx.x * gpb, last = min(P, first + gpb);
     for (int tbase = 0; tbase < T; tbase += TCHUNK) {
         const int tn = min(TCHUNK, T - tbase);
-        for (int t = threadIdx.x; t < tn; t += 256) s_hist[t] = 0;
+        for (int t = threadIdx.x; t < tn; t += SLICE_THREADS) s_hist[t] = 0;
         __syncthreads();
-        for (int idx = first + threadIdx.x; idx < last; idx += 256) {
+        for (int idx = first + threadIdx.x; idx < last; idx += SLICE_THREADS) {
             const SliceRect r = load_rect(splat, idx, gx, gy);
             if (!r.visible) continue;
             for (uint32_t y = r.mny; y < r.mxy; y++)
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(256) tile_count_kernel(int P, int gpb, int gx,
         }
         __syncthreads();
         uint32_t* row = table + (size_t)blockIdx.x * T + tbase;
-        for (int t = threadIdx.x; t < tn; t += 256) row[t] = s_hist[t];
+        for (int t = threadIdx.x; t < tn; t += SLICE_THREADS) row[t] = s_hist[t];
         __syncthreads();
     }
 }
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(1024) tile_starts_kernel(int T, const uint32_t
 }
 
 // (4) scatter (depth bits, id) into the tile segments.  Same slicing and LDS size as (1).
-__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
+__global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
                                                            const uint32_t* __restrict__ table, const uint32_t* __restrict__ starts,
                                                            uint2* __restrict__ bins)
 {
@@ -150,9 +153,9 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int gpb, int g
     for (int tbase = 0; tbase < T; tbase += TCHUNK) {
         const int tn = min(TCHUNK, T - tbase);
         const uint32_t* row = table + (size_t)blockIdx.x * T + tbase;
-        for (int t = threadIdx.x; t < tn; t += 256) s_cur[t] = row[t] + starts[tbase + t];
+        for (int t = threadIdx.x; t < tn; t += SLICE_THREADS) s_cur[t] = row[t] + starts[tbase + t];
         __syncthreads();
-        for (int idx = first + threadIdx.x; idx < last; idx += 256) {
+        for (int idx = first + threadIdx.x; idx < last; idx += SLICE_THREADS) {
             const SliceRect r = load_rect(splat, idx, gx, gy);
             if (!r.visible) continue;
             for (uint32_t y = r.mny; y < r.mxy; y++)
@@ -414,10 +417,10 @@ void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* 
     int gpb;
     const int ns = gsr_tile_slices(P, &gpb);
     const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(256), lds, s, P, gpb, gx, gy, T, splat, table);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table);
     hipLaunchKernelGGL(tile_colscan_kernel, dim3((T + 31) / 32), dim3(256), 0, s, T, ns, table, totals);
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(1024), 0, s, T, totals, starts, ranges);
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(256), lds, s, P, gpb, gx, gy, T, splat, table, starts,
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table, starts,
                        reinterpret_cast<uint2*>(bins));
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<const unsigned long long*>(bins),
                        point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
