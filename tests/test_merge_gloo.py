@@ -84,3 +84,23 @@ def test_pack_block_matches_ply_column_order():
     # scene/gaussian_model.py:208-209: transpose(1, 2).flatten(start_dim=1)
     assert torch.equal(blk[:, 6:51], f_rest.transpose(1, 2).flatten(start_dim=1))
     assert torch.equal(blk[:, 51:52], op) and torch.equal(blk[:, 55:], rot)
+
+
+def test_partition_layout_of_the_multi_gpu_benchmark():
+    """bench.py --gpus N: rank r owns origin_box r of a 4-column grid, Gaussians cover the box + 10 % margin
+    (scene/ptgs/shen_partation_densify.py:182-252), and cropping every partition to its box keeps disjoint sets."""
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    world = 8
+    boxes = [syn.partition_origin_box(r, world) for r in range(world)]
+    assert boxes[0] == (-4.0, 4.0, -4.0, 4.0) and boxes[3][0] == 20.0 and boxes[4] == (-4.0, 4.0, 4.0, 12.0)
+    kept = []
+    for r in range(world):
+        g, centre, box = syn.make_partition(r, world, 2000, seed=0)
+        x0, x1, y0, y1 = box
+        assert abs(centre[0] - 0.5 * (x0 + x1)) < 1e-6 and g.xyz[:, 0].min() < x0 and g.xyz[:, 0].max() > x1  # overlap margin
+        m = merge.crop_mask(g.xyz, (x0, y0, x1, y1))
+        assert 0.6 < m.float().mean() < 0.8  # (1/1.2)^2 of the expanded box
+        kept.append(g.xyz[m])
+    allxyz = torch.cat(kept)
+    assert torch.unique(allxyz, dim=0).shape[0] == allxyz.shape[0]
