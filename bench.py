@@ -226,6 +226,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # scene initialisation kernel of the path (distCUDA2, once per sub-scene): reported next to the step, not part of it
+    from based_on_point_cloud_partitions_amd import distCUDA2
+    distCUDA2(xyz.detach())
+    torch.cuda.synchronize()
+    tk = time.perf_counter()
+    distCUDA2(xyz.detach())
+    torch.cuda.synchronize()
+    knn_ms = round(1e3 * (time.perf_counter() - tk), 3)
+
     full = None
     if args.full_step:
         full = full_step_timing(args, rasterizers, params, (xyz, scales, rots, opac, shs), H, W, dev)
@@ -247,6 +256,19 @@ def main():
             kernels.append({"kernel": name, "avg_ms": round(avg_ms, 4), "launches": n,
                             "algorithmic_MB": round(sb[name] / 1e6, 2),
                             "achieved_GBs": round(sb[name] / 1e9 / (avg_ms * 1e-3), 1)})
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pass
+        for k in kernels:
+            v = pmc.get(k["kernel"], {})
+            if "sq_insts_valu" in v:
+                # wave64 VALU issue peak: one instruction per 2 cycles per SIMD (MI355X_MICROARCH.md), 1024 SIMDs, 2.4 GHz
+                k["valu_insts"] = int(v["sq_insts_valu"])
+                k["valu_issue_frac"] = round(v["sq_insts_valu"] * 2.0 / (1024 * 2.4e9 * k["avg_ms"] * 1e-3), 3)
+            if "hbm_bytes" in v:
+                k["hbm_traffic_MB"] = round(v["hbm_bytes"] / 1e6, 1)
         kernels.sort(key=lambda k: -k["avg_ms"])
         roofline = None
         if kernels:
@@ -277,6 +299,7 @@ def main():
                                "tile_list_mean": round(float(np.mean([u["tile_mean"] for u in used])), 1),
                                "tile_list_max": int(max(u["tile_max"] for u in used)),
                                "n_contrib_mean": round(float(np.mean([u["n_contrib_mean"] for u in used])), 1)},
+            "knn_init_ms": knn_ms,
             "rendered_mpix_per_s_fwd": round(world * N / 1e6 / (fwd_ms * 1e-3), 1) if fwd_ms > 0 else None,
             "roofline": roofline,
             "roofline_step": {"bound": "hbm", "algorithmic_bytes": int(step_bytes),

@@ -13,5 +13,6 @@ grep '^{' $out/bench.log > $out/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o stats -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline > $out/stats.log 2>&1 || exit 2
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out -o fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > $out/fetch.log 2>&1 || exit 3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out -o write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > $out/write.log 2>&1 || exit 4
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $out -o sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timers > $out/sq.log 2>&1 || exit 5
 rm -f $out/stats_kernel_trace.csv
 ls -la $out

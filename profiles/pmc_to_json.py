@@ -16,7 +16,7 @@ import sys
 STAGE = {
     "preprocess_kernel": "preprocess", "scan_blocks_kernel": "scan", "emit_keys_kernel": "emit_keys",
     "tile_count_kernel": "radix_sort", "tile_colscan_kernel": "radix_sort", "tile_starts_kernel": "radix_sort",
-    "tile_scatter_kernel": "radix_sort", "tile_sort_kernel": "radix_sort", "global_hist_kernel": "radix_sort",
+    "tile_scatter_kernel": "radix_sort", "tile_sort_small_kernel": "radix_sort", "tile_sort_large_kernel": "radix_sort", "global_hist_kernel": "radix_sort",
     "block_hist_kernel": "radix_sort", "bin_scan_kernel": "radix_sort", "scatter_kernel": "radix_sort",
     "tile_ranges_kernel": "tile_ranges", "render_forward_kernel": "render_forward", "render_backward_kernel": "render_backward",
     "gaussian_backward_kernel": "gaussian_backward",
@@ -44,6 +44,13 @@ def main(d, out):
             res[st]["fetch_size_kib"] += f[k] * mult
         if k in w:
             res[st]["write_size_kib"] += w[k] * mult
+    import os
+    sqp = f"{d}/sq_counter_collection.csv"
+    sq = {c: load(sqp, c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES")} if os.path.exists(sqp) else {}
+    for c, per in sq.items():
+        for k, st in STAGE.items():
+            if k in per:
+                res[st][c.lower()] = res[st].get(c.lower(), 0.0) + per[k] * launches_per_step.get(k, 1)
     outd = {}
     for st, v in res.items():
         outd[st] = {"hbm_bytes": int((2 * v["fetch_size_kib"] + v["write_size_kib"]) * 1024), **{a: round(b, 1) for a, b in v.items()},
