@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -39,6 +39,12 @@ PROTOTYPES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_size,
                              c_void_p, c_size, c_void_p, c_size, c_void_p, c_size, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_forward_params": (c_int, [c_int, c_int, c_int] + [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_float, c_float, c_void_p, c_void_p, c_size, c_void_p, c_size, c_void_p, c_size, c_void_p,
+                                   ctypes.POINTER(c_i64), c_void_p]),
+    "gsr_backward_params": (c_int, [c_int, c_int, c_int, c_i64, c_int, c_int] + [c_void_p] * 6 + [c_float, c_void_p, c_void_p,
+                                    c_void_p, c_float, c_float, c_void_p, c_void_p, c_size, c_void_p, c_size, c_void_p, c_size,
+                                    c_void_p, c_size] + [c_void_p] * 9),
     "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_loss_scratch_bytes": (c_size, [c_int, c_int, c_int]),
     "gsr_loss_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p]),

@@ -137,34 +137,14 @@ size_t gsr_image_bytes(int W, int H) { return gsr_image_layout(W, H).bytes; }
 size_t gsr_binning_bytes(int64_t R, int P, int W, int H) { return gsr_bin_layout((long)R, P, W, H).bytes; }
 size_t gsr_backward_scratch_bytes(int64_t R) { return gsr_align((size_t)(R > 0 ? R : 1) * GSR_GROW_F * 4); }
 
-int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
-                         const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
-                         const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
-                         int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* geom_buffer,
-                         size_t geom_bytes, int64_t* num_rendered_host, void* stream)
+// Phase 1 shared by gsr_forward_geometry and gsr_forward_params: `a` carries the inputs, the outputs inside the geometry
+// buffer are filled in here.
+static int run_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_bytes, int64_t* num_rendered_host, hipStream_t s)
 {
-    (void)prefiltered;  // only selects a device-side trap in the reference (auxiliary.h:156-160)
-    hipStream_t s = (hipStream_t)stream;
-    if (!num_rendered_host) return fail(-1, "num_rendered_host is NULL");
-    *num_rendered_host = 0;
-    if (P < 0 || W <= 0 || H <= 0) return fail(-1, "invalid sizes");
-    if (P == 0) return 0;
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer)
-        return fail(-1, "NULL required pointer");
-    if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(-2, "provide exactly one of shs / colors_precomp");
-    if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
-        return fail(-2, "provide scales+rotations or cov3D_precomp");
-    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(-2, "SH degree / coefficient count mismatch");
+    const int P = a.P;
     const GeomLayout L = gsr_geom_layout(P);
     if (geom_bytes < L.bytes) return fail(-3, "geometry buffer too small");
     char* g = (char*)geom_buffer;
-    PreprocessArgs a;
-    a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
-    a.means3D = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.shs = shs;
-    a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
-    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
-    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
-    a.radii = radii;
     a.splat = (float*)(g + L.splat); a.cov3D = (float*)(g + L.cov3D); a.clamped = (uint8_t*)(g + L.clamped);
     a.tiles_touched = (uint32_t*)(g + L.tiles_touched); a.block_sums = (uint32_t*)(g + L.block_sums);
     { StageTimer t(GSR_STAGE_PREPROCESS, s); gsr_launch_preprocess(a, s); }
@@ -184,6 +164,35 @@ int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float*
     }
     *num_rendered_host = (int64_t)total;
     return check_hip("forward_geometry");
+}
+
+int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                         const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                         const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                         int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* geom_buffer,
+                         size_t geom_bytes, int64_t* num_rendered_host, void* stream)
+{
+    (void)prefiltered;  // only selects a device-side trap in the reference (auxiliary.h:156-160)
+    hipStream_t s = (hipStream_t)stream;
+    if (!num_rendered_host) return fail(-1, "num_rendered_host is NULL");
+    *num_rendered_host = 0;
+    if (P < 0 || W <= 0 || H <= 0) return fail(-1, "invalid sizes");
+    if (P == 0) return 0;
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer)
+        return fail(-1, "NULL required pointer");
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(-2, "provide exactly one of shs / colors_precomp");
+    if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
+        return fail(-2, "provide scales+rotations or cov3D_precomp");
+    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(-2, "SH degree / coefficient count mismatch");
+    PreprocessArgs a;
+    a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
+    a.means3D = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.shs = shs;
+    a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
+    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.radii = radii;
+    a.raw = 0; a.features_dc = nullptr; a.features_rest = nullptr;
+    return run_geometry(a, geom_buffer, geom_bytes, num_rendered_host, s);
 }
 
 int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, void* geom_buffer, size_t geom_bytes,
@@ -269,22 +278,45 @@ int gsr_forward(int P, int D, int M, const float* background, const float* means
                               image_bytes, out_color, stream);
 }
 
-int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
-                 size_t geom_bytes, const void* binning_buffer, size_t binning_bytes, const void* image_buffer,
-                 size_t image_bytes, void* scratch, size_t scratch_bytes, const float* dL_dpix, float* dL_dmeans2D,
-                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                 float* dL_dscales, float* dL_drotations, void* stream)
+int gsr_forward_params(int P, int D, int M, const float* background, const float* xyz, const float* features_dc,
+                       const float* features_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
+                       float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H,
+                       float tan_fovx, float tan_fovy, int* radii, void* geom_buffer, size_t geom_bytes, void* binning_buffer,
+                       size_t binning_bytes, void* image_buffer, size_t image_bytes, float* out_color, int64_t* num_rendered_host,
+                       void* stream)
 {
-    (void)colors_precomp;
     hipStream_t s = (hipStream_t)stream;
+    if (!num_rendered_host) return fail(-1, "num_rendered_host is NULL");
+    *num_rendered_host = 0;
+    if (P < 0 || W <= 0 || H <= 0) return fail(-1, "invalid sizes");
     if (P == 0) return 0;
-    if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer || !dL_dpix ||
-        !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations)
+    if (!xyz || !features_dc || !opacity_raw || !scaling_raw || !rotation_raw || !viewmatrix || !projmatrix || !campos || !radii ||
+        !geom_buffer)
         return fail(-1, "NULL required pointer");
-    if (M > 0 && !dL_dsh) return fail(-1, "dL_dsh is NULL");
+    if (D < 0 || D > 3 || M < (D + 1) * (D + 1)) return fail(-2, "SH degree / coefficient count mismatch");
+    if (M > 1 && !features_rest) return fail(-1, "features_rest is NULL");
+    PreprocessArgs a;
+    a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
+    a.means3D = xyz; a.scales = scaling_raw; a.rotations = rotation_raw; a.opacities = opacity_raw; a.shs = nullptr;
+    a.cov3D_precomp = nullptr; a.colors_precomp = nullptr;
+    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.radii = radii;
+    a.raw = 1; a.features_dc = features_dc; a.features_rest = features_rest;
+    const int rc = run_geometry(a, geom_buffer, geom_bytes, num_rendered_host, s);
+    if (rc != 0) return rc;
+    const int64_t R = *num_rendered_host;
+    if (R > 0 && gsr_bin_layout((long)R, P, W, H).bytes > binning_bytes) return 1;  // caller re-allocates and calls gsr_forward_render
+    return gsr_forward_render(P, R, W, H, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer,
+                              image_bytes, out_color, stream);
+}
+
+// Shared by gsr_backward and gsr_backward_params: `a` carries the per-Gaussian inputs and the output pointers.
+static int run_backward(GaussBackwardArgs a, int64_t R, const float* background, const void* geom_buffer, size_t geom_bytes,
+                        const void* binning_buffer, size_t binning_bytes, const void* image_buffer, size_t image_bytes,
+                        void* scratch, size_t scratch_bytes, const float* dL_dpix, const float* cov3D_precomp, hipStream_t s)
+{
+    const int P = a.P, W = a.W, H = a.H;
     const GeomLayout G = gsr_geom_layout(P);
     const ImageLayout I = gsr_image_layout(W, H);
     const BinLayout B = gsr_bin_layout((long)R, P, W, H);
@@ -304,21 +336,73 @@ int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* back
                                    (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
                                    (const uint8_t*)(b + B.flags), (float*)scratch, s);
     }
+    a.cov3D_in = cov3D_precomp ? cov3D_precomp : (const float*)(g + G.cov3D);
+    a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);
+    a.tiles_touched = (const uint32_t*)(g + G.tiles_touched);
+    a.point_offsets = (const uint32_t*)(g + G.point_offsets);
+    a.grad_rows = (const float*)scratch;
+    { StageTimer t(GSR_STAGE_GAUSS_BWD, s); gsr_launch_gaussian_backward(a, s); }
+    return check_hip("backward");
+}
+
+int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
+                 size_t geom_bytes, const void* binning_buffer, size_t binning_bytes, const void* image_buffer,
+                 size_t image_bytes, void* scratch, size_t scratch_bytes, const float* dL_dpix, float* dL_dmeans2D,
+                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscales, float* dL_drotations, void* stream)
+{
+    (void)colors_precomp;
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return 0;
+    if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer || !dL_dpix ||
+        !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations)
+        return fail(-1, "NULL required pointer");
+    if (M > 0 && !dL_dsh) return fail(-1, "dL_dsh is NULL");
     GaussBackwardArgs a;
     a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
     a.means3D = means3D; a.shs = shs; a.scales = scales; a.rotations = rotations;
-    a.cov3D_in = cov3D_precomp ? cov3D_precomp : (const float*)(g + G.cov3D);
     a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
-    a.radii = radii; a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);
-    a.tiles_touched = (const uint32_t*)(g + G.tiles_touched);
-    a.point_offsets = (const uint32_t*)(g + G.point_offsets);
+    a.radii = radii;
     a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
     a.has_shs = shs != nullptr; a.has_scales = scales != nullptr;
-    a.grad_rows = (const float*)scratch;
     a.dL_dmeans2D = dL_dmeans2D; a.dL_dcolors = dL_dcolors; a.dL_dopacity = dL_dopacity; a.dL_dmeans3D = dL_dmeans3D;
     a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales; a.dL_drots = dL_drotations;
-    { StageTimer t(GSR_STAGE_GAUSS_BWD, s); gsr_launch_gaussian_backward(a, s); }
-    return check_hip("backward");
+    a.raw = 0; a.features_dc = nullptr; a.features_rest = nullptr; a.dL_dfeatures_dc = nullptr; a.dL_dfeatures_rest = nullptr;
+    return run_backward(a, R, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer, image_bytes, scratch,
+                        scratch_bytes, dL_dpix, cov3D_precomp, s);
+}
+
+int gsr_backward_params(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* xyz,
+                        const float* features_dc, const float* features_rest, const float* scaling_raw, const float* rotation_raw,
+                        float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                        float tan_fovy, const int* radii, const void* geom_buffer, size_t geom_bytes, const void* binning_buffer,
+                        size_t binning_bytes, const void* image_buffer, size_t image_bytes, void* scratch, size_t scratch_bytes,
+                        const float* dL_dpix, float* dL_dmeans2D, float* dL_dxyz, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
+                        float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return 0;
+    if (!background || !xyz || !features_dc || !scaling_raw || !rotation_raw || !viewmatrix || !projmatrix || !campos || !radii ||
+        !geom_buffer || !image_buffer || !dL_dpix || !dL_dmeans2D || !dL_dxyz || !dL_dfeatures_dc || !dL_dopacity_raw ||
+        !dL_dscaling_raw || !dL_drotation_raw)
+        return fail(-1, "NULL required pointer");
+    if (M < 1 || (M > 1 && (!features_rest || !dL_dfeatures_rest))) return fail(-1, "features_rest / dL_dfeatures_rest is NULL");
+    GaussBackwardArgs a;
+    a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
+    a.means3D = xyz; a.shs = nullptr; a.scales = scaling_raw; a.rotations = rotation_raw;
+    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
+    a.radii = radii;
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.has_shs = 1; a.has_scales = 1;
+    a.dL_dmeans2D = dL_dmeans2D; a.dL_dcolors = nullptr; a.dL_dopacity = dL_dopacity_raw; a.dL_dmeans3D = dL_dxyz;
+    a.dL_dcov3D = nullptr; a.dL_dsh = nullptr; a.dL_dscales = dL_dscaling_raw; a.dL_drots = dL_drotation_raw;
+    a.raw = 1; a.features_dc = features_dc; a.features_rest = features_rest;
+    a.dL_dfeatures_dc = dL_dfeatures_dc; a.dL_dfeatures_rest = dL_dfeatures_rest;
+    return run_backward(a, R, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer, image_bytes, scratch,
+                        scratch_bytes, dL_dpix, nullptr, s);
 }
 
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

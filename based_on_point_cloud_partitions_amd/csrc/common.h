@@ -118,6 +118,10 @@ struct PreprocessArgs {
     float scale_modifier, tan_fovx, tan_fovy;
     int* radii;
     float* splat; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched; uint32_t* block_sums;
+    // raw-parameter mode (gsr_forward_params): scales / rotations / opacities hold the PRE-activation parameters of
+    // scene/gaussian_model.py:102-122 and the SH rows come from the two tensors features_dc [P][1][3] / features_rest [P][M-1][3]
+    int raw;
+    const float *features_dc, *features_rest;
 };
 void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
@@ -146,6 +150,11 @@ struct GaussBackwardArgs {
     int has_shs, has_scales;
     const float* grad_rows;
     float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
+    // raw-parameter mode (gsr_backward_params): scales / rotations are pre-activation, gradients are w.r.t. the raw
+    // parameters, dL_dsh is split into dL_dfeatures_dc / dL_dfeatures_rest; dL_dcolors / dL_dcov3D may be NULL
+    int raw;
+    const float *features_dc, *features_rest;
+    float *dL_dfeatures_dc, *dL_dfeatures_rest;
 };
 void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s);
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
@@ -216,6 +225,53 @@ __device__ __forceinline__ void sh_tile_store(float* __restrict__ g, const float
         }
     }
 }
+
+// Same for a column range [col0, col0 + ncols) of the LDS rows whose global source/destination is its own dense
+// [rows][ncols] array (features_dc / features_rest and their gradients).  `g` must be 16-byte aligned (it is: a
+// workgroup's base offset is a multiple of 256 rows); a float4 may straddle rows, so the row/column is stepped per element.
+__device__ __forceinline__ void sh_cols_load(const float* __restrict__ g, float* __restrict__ s, int rows, int ncols, int stride, int col0)
+{
+    const int count = rows * ncols, n4 = count >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int f = threadIdx.x; f < n4; f += 256) {
+        const float4 v = g4[f];
+        const float e4[4] = {v.x, v.y, v.z, v.w};
+        int r = (f << 2) / ncols, c = (f << 2) - r * ncols;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            s[r * stride + col0 + c] = e4[k];
+            if (++c == ncols) { c = 0; r++; }
+        }
+    }
+    for (int e = (n4 << 2) + threadIdx.x; e < count; e += 256) {
+        const int r = e / ncols, c = e - r * ncols;
+        s[r * stride + col0 + c] = g[e];
+    }
+}
+__device__ __forceinline__ void sh_cols_store(float* __restrict__ g, const float* __restrict__ s, int rows, int ncols, int stride, int col0)
+{
+    const int count = rows * ncols, n4 = count >> 2;
+    float4* g4 = reinterpret_cast<float4*>(g);
+    for (int f = threadIdx.x; f < n4; f += 256) {
+        float e4[4];
+        int r = (f << 2) / ncols, c = (f << 2) - r * ncols;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            e4[k] = s[r * stride + col0 + c];
+            if (++c == ncols) { c = 0; r++; }
+        }
+        g4[f] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+    }
+    for (int e = (n4 << 2) + threadIdx.x; e < count; e += 256) {
+        const int r = e / ncols, c = e - r * ncols;
+        g[e] = s[r * stride + col0 + c];
+    }
+}
+
+// Activations of scene/gaussian_model.py:33-40 in the arithmetic the oracle restates (oracle/gs_oracle.c, orc_activate):
+// scaling = exp, opacity = sigmoid, rotation = x / max(||x||, 1e-12) (torch.nn.functional.normalize).
+__device__ __forceinline__ float gsr_sigmoidf(float x) { return 1.0f / (1.0f + gsr_expf(-x)); }
+__device__ __forceinline__ float gsr_quat_norm(float r, float x, float y, float z) { return sqrtf(((r * r + x * x) + y * y) + z * z); }
 
 // Conservative tile-level rejection used while staging a tile's list: returns true only if NO pixel centre of the
 // 16x16 tile whose first pixel is (x0, y0) can reach power >= pthr, i.e. alpha >= 1/255 (power = -0.5*q,

@@ -32,10 +32,16 @@ struct GaussBackwardPtrs {
     float* __restrict__ dL_dmeans2D; float* __restrict__ dL_dcolors; float* __restrict__ dL_dopacity;
     float* __restrict__ dL_dmeans3D; float* __restrict__ dL_dcov3D; float* __restrict__ dL_dsh; float* __restrict__ dL_dscales;
     float* __restrict__ dL_drots;
+    const float* __restrict__ features_dc; const float* __restrict__ features_rest;
+    float* __restrict__ dL_dfeatures_dc; float* __restrict__ dL_dfeatures_rest;
     int P, D, M, has_shs, has_scales, dbg, lds_floats;
     float scale_modifier, tan_fovx, tan_fovy;
 };
 
+// RAW (gsr_backward_params): scales / rotations are the pre-activation parameters; the chain rule through exp / sigmoid /
+// normalize is applied here and dL/dSH leaves LDS as the two tensors dL/dfeatures_dc, dL/dfeatures_rest -- the autograd
+// passes of scene/gaussian_model.py:102-122 (exp, sigmoid, normalize, cat backward) never touch HBM.
+template <bool RAW>
 __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
 {
     extern __shared__ float s_tile[];  // [256][3M + 1]
@@ -79,7 +85,10 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
         }
     }
 
-    if (a.has_shs && !(a.dbg & 2)) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
+    if (RAW) {
+        sh_cols_load(a.features_dc + (size_t)blockIdx.x * 256 * 3, s_tile, rows, 3, stride, 0);
+        if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * 256 * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
+    } else if (a.has_shs && !(a.dbg & 2)) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
     __syncthreads();
     float* __restrict__ my_row = s_tile + threadIdx.x * stride;  // SH in, dL/dSH out
 
@@ -96,8 +105,12 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
     const float dLc_x = g[GR_CX], dLc_y = g[GR_CY], dLc_w = g[GR_CW];
     float dL_dcol[3] = {g[GR_R], g[GR_G], g[GR_B]};
     o_m2[0] = dL_dmean2D_x; o_m2[1] = dL_dmean2D_y; o_m2[2] = 0.f;
-    o_col[0] = dL_dcol[0]; o_col[1] = dL_dcol[1]; o_col[2] = dL_dcol[2];
-    a.dL_dopacity[idx] = g[GR_OPA];
+    if (!RAW || a.dL_dcolors) { o_col[0] = dL_dcol[0]; o_col[1] = dL_dcol[1]; o_col[2] = dL_dcol[2]; }
+    if (RAW) {  // d sigmoid: y (1 - y), y = the activated opacity kept in the splat record
+        const float opa = a.splat[(size_t)idx * GSR_SPLAT_F + SP_OPA];
+        a.dL_dopacity[idx] = g[GR_OPA] * ((1.0f - opa) * opa);
+    } else
+        a.dL_dopacity[idx] = g[GR_OPA];
 
     const float* v = a.viewmatrix;
     const float* proj = a.projmatrix;
@@ -150,7 +163,8 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
     } else {
         for (int i = 0; i < 6; i++) dcv[i] = 0;
     }
-    for (int i = 0; i < 6; i++) o_cov[i] = dcv[i];
+    if (!RAW || a.dL_dcov3D)
+        for (int i = 0; i < 6; i++) o_cov[i] = dcv[i];
     // Vrk is symmetric: Vrk[0]=(c0,c1,c2), Vrk[1]=(c1,c3,c4), Vrk[2]=(c2,c4,c5)
     const float dL_dT00 = 2 * (T00 * c0 + T01 * c1 + T02 * c2) * dL_da + (T10 * c0 + T11 * c1 + T12 * c2) * dL_db;
     const float dL_dT01 = 2 * (T00 * c1 + T01 * c3 + T02 * c4) * dL_da + (T10 * c1 + T11 * c3 + T12 * c4) * dL_db;
@@ -262,14 +276,21 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
 
     if (a.has_scales) {
         // computeCov3D backward (backward.cu:278-341)
-        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+        float qn = 1.0f;
+        if (RAW) {
+            sc[0] = gsr_expf(sc[0]); sc[1] = gsr_expf(sc[1]); sc[2] = gsr_expf(sc[2]);
+            qn = gsr_quat_norm(q.x, q.y, q.z, q.w);
+            const float d = fmaxf(qn, 1e-12f);
+            q.x = q.x / d; q.y = q.y / d; q.z = q.z / d; q.w = q.w / d;
+        }
         const float r = q.x, x = q.y, y = q.z, z = q.w;
         const float Rq[3][3] = {
             {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
             {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
             {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-        const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-                            a.scale_modifier * a.scales[3 * idx + 2]};
+        const float s[3] = {a.scale_modifier * sc[0], a.scale_modifier * sc[1], a.scale_modifier * sc[2]};
         float Mm[3][3];
         for (int c = 0; c < 3; c++)
             for (int k = 0; k < 3; k++) Mm[c][k] = s[k] * Rq[c][k];
@@ -279,7 +300,10 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
         for (int c = 0; c < 3; c++)
             for (int rr = 0; rr < 3; rr++)
                 dMt[rr][c] = (2.0f * Mm[0][rr]) * dS[c][0] + (2.0f * Mm[1][rr]) * dS[c][1] + (2.0f * Mm[2][rr]) * dS[c][2];
-        for (int c = 0; c < 3; c++) o_sc[c] = Rq[0][c] * dMt[c][0] + Rq[1][c] * dMt[c][1] + Rq[2][c] * dMt[c][2];
+        for (int c = 0; c < 3; c++) {
+            const float ds = Rq[0][c] * dMt[c][0] + Rq[1][c] * dMt[c][1] + Rq[2][c] * dMt[c][2];
+            o_sc[c] = RAW ? ds * sc[c] : ds;  // d exp: y
+        }
         for (int c = 0; c < 3; c++)
             for (int rr = 0; rr < 3; rr++) dMt[c][rr] *= s[c];
         float4 dq;
@@ -287,6 +311,15 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
         dq.y = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
         dq.z = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
         dq.w = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+        if (RAW) {  // d normalize: (g - q (q.g)) / ||v||, or g / eps below the clamp
+            if (qn > 1e-12f) {
+                const float dot = ((q.x * dq.x + q.y * dq.y) + q.z * dq.z) + q.w * dq.w;
+                dq.x = (dq.x - q.x * dot) / qn; dq.y = (dq.y - q.y * dot) / qn;
+                dq.z = (dq.z - q.z * dot) / qn; dq.w = (dq.w - q.w * dot) / qn;
+            } else {
+                dq.x = dq.x / 1e-12f; dq.y = dq.y / 1e-12f; dq.z = dq.z / 1e-12f; dq.w = dq.w / 1e-12f;
+            }
+        }
         reinterpret_cast<float4*>(o_rot)[0] = dq;
     } else {
         o_sc[0] = 0.f; o_sc[1] = 0.f; o_sc[2] = 0.f;
@@ -299,16 +332,20 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
         float* __restrict__ o_cov = a.dL_dcov3D + 6 * (size_t)idx;
         float* __restrict__ o_sc = a.dL_dscales + 3 * (size_t)idx;
         o_m2[0] = 0.f; o_m2[1] = 0.f; o_m2[2] = 0.f;
-        o_col[0] = 0.f; o_col[1] = 0.f; o_col[2] = 0.f;
+        if (!RAW || a.dL_dcolors) { o_col[0] = 0.f; o_col[1] = 0.f; o_col[2] = 0.f; }
         a.dL_dopacity[idx] = 0.f;
         o_m3[0] = 0.f; o_m3[1] = 0.f; o_m3[2] = 0.f;
-        for (int i = 0; i < 6; i++) o_cov[i] = 0.f;
+        if (!RAW || a.dL_dcov3D)
+            for (int i = 0; i < 6; i++) o_cov[i] = 0.f;
         for (int i = 0; i < n3; i++) my_row[i] = 0.f;
         o_sc[0] = 0.f; o_sc[1] = 0.f; o_sc[2] = 0.f;
         reinterpret_cast<float4*>(a.dL_drots + 4 * (size_t)idx)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    if (n3 > 0 && !(a.dbg & 4)) sh_tile_store(a.dL_dsh + tile_base, s_tile, rows, n3, stride);
+    if (RAW) {
+        sh_cols_store(a.dL_dfeatures_dc + (size_t)blockIdx.x * 256 * 3, s_tile, rows, 3, stride, 0);
+        if (n3 > 3) sh_cols_store(a.dL_dfeatures_rest + (size_t)blockIdx.x * 256 * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
+    } else if (n3 > 0 && !(a.dbg & 4)) sh_tile_store(a.dL_dsh + tile_base, s_tile, rows, n3, stride);
 }
 
 }  // namespace
@@ -323,11 +360,16 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.splat = a.splat; p.tiles_touched = a.tiles_touched; p.grad_rows = a.grad_rows; p.point_offsets = a.point_offsets;
     p.dL_dmeans2D = a.dL_dmeans2D; p.dL_dcolors = a.dL_dcolors; p.dL_dopacity = a.dL_dopacity; p.dL_dmeans3D = a.dL_dmeans3D;
     p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscales = a.dL_dscales; p.dL_drots = a.dL_drots;
+    p.features_dc = a.features_dc; p.features_rest = a.features_rest;
+    p.dL_dfeatures_dc = a.dL_dfeatures_dc; p.dL_dfeatures_rest = a.dL_dfeatures_rest;
     p.P = a.P; p.D = a.D; p.M = a.M; p.has_shs = a.has_shs; p.has_scales = a.has_scales;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     p.dbg = gsr_variant("GB_DBG", 0);
     size_t lds = (size_t)256 * (3 * a.M + 1) * 4;
     if (lds < 1024 * GSR_GROW_F * 4) lds = 1024 * GSR_GROW_F * 4;  // room for 1024 gradient rows per chunk
     p.lds_floats = (int)(lds / 4);
-    hipLaunchKernelGGL(gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
+    if (a.raw)
+        hipLaunchKernelGGL(gaussian_backward_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
+    else
+        hipLaunchKernelGGL(gaussian_backward_kernel<false>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
 }

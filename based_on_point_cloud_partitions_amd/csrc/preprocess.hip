@@ -61,12 +61,16 @@ struct PreprocessPtrs {
     const float* __restrict__ means3D; const float* __restrict__ scales; const float* __restrict__ rotations;
     const float* __restrict__ opacities; const float* __restrict__ shs; const float* __restrict__ cov3D_precomp;
     const float* __restrict__ colors_precomp; const float* __restrict__ viewmatrix; const float* __restrict__ projmatrix;
-    const float* __restrict__ campos;
+    const float* __restrict__ campos; const float* __restrict__ features_dc; const float* __restrict__ features_rest;
     float scale_modifier, tan_fovx, tan_fovy;
     int* __restrict__ radii; float* __restrict__ splat; float* __restrict__ cov3D; uint8_t* __restrict__ clamped;
     uint32_t* __restrict__ tiles_touched; uint32_t* __restrict__ block_sums;
 };
 
+// RAW: scales / rotations / opacities are the pre-activation parameters (exp / normalize / sigmoid applied here) and the
+// SH rows are assembled in LDS from features_dc + features_rest -- the four activation passes and the 96 MB torch.cat of
+// scene/gaussian_model.py:102-122 never touch HBM.
+template <bool RAW>
 __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float focal_x, float focal_y, int gx, int gy)
 {
     // SH rows are 192 B per Gaussian: the workgroup's 256 rows come in through LDS with coalesced 16-byte loads and are read
@@ -74,7 +78,12 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
     extern __shared__ float s_sh[];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n3 = 3 * a.M, sh_stride = n3 + 1;
-    if (a.shs) {
+    if (RAW) {
+        const int rows = min(256, a.P - (int)blockIdx.x * 256);
+        sh_cols_load(a.features_dc + (size_t)blockIdx.x * 256 * 3, s_sh, rows, 3, sh_stride, 0);
+        if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * 256 * (n3 - 3), s_sh, rows, n3 - 3, sh_stride, 3);
+        __syncthreads();
+    } else if (a.shs) {
         sh_tile_load(a.shs + (size_t)blockIdx.x * 256 * n3, s_sh, min(256, a.P - (int)blockIdx.x * 256), n3, sh_stride);
         __syncthreads();
     }
@@ -101,9 +110,14 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
                 c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
             } else {
                 // computeCov3D (forward.cu:118-152): Sigma = Rq S^2 Rq^T with GLM's summation order
-                const float s0 = a.scale_modifier * a.scales[3 * idx], s1 = a.scale_modifier * a.scales[3 * idx + 1],
-                            s2 = a.scale_modifier * a.scales[3 * idx + 2];
-                const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+                float sc0 = a.scales[3 * idx], sc1 = a.scales[3 * idx + 1], sc2 = a.scales[3 * idx + 2];
+                float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+                if (RAW) {
+                    sc0 = gsr_expf(sc0); sc1 = gsr_expf(sc1); sc2 = gsr_expf(sc2);
+                    const float d = fmaxf(gsr_quat_norm(q.x, q.y, q.z, q.w), 1e-12f);
+                    q.x = q.x / d; q.y = q.y / d; q.z = q.z / d; q.w = q.w / d;
+                }
+                const float s0 = a.scale_modifier * sc0, s1 = a.scale_modifier * sc1, s2 = a.scale_modifier * sc2;
                 const float r = q.x, x = q.y, y = q.z, z = q.w;
                 const float m00 = s0 * (1.f - 2.f * (y * y + z * z)), m01 = s1 * (2.f * (x * y - r * z)), m02 = s2 * (2.f * (x * z + r * y));
                 const float m10 = s0 * (2.f * (x * y + r * z)), m11 = s1 * (1.f - 2.f * (x * x + z * z)), m12 = s2 * (2.f * (y * z - r * x));
@@ -171,7 +185,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
                         a.clamped[3 * idx] = cl[0]; a.clamped[3 * idx + 1] = cl[1]; a.clamped[3 * idx + 2] = cl[2];
                     }
                     rec0 = make_float4(pix_x, pix_y, conx, cony);
-                    rec1 = make_float4(conz, a.opacities[idx], cr, cg);
+                    const float opa = RAW ? gsr_sigmoidf(a.opacities[idx]) : a.opacities[idx];
+                    rec1 = make_float4(conz, opa, cr, cg);
                     rec2 = make_float4(cb, tz, __int_as_float(iradius), 0.0f);
                     radius_out = iradius;
                     touched = area;
@@ -313,9 +328,12 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     p.projmatrix = a.projmatrix; p.campos = a.campos;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     p.radii = a.radii; p.splat = a.splat; p.cov3D = a.cov3D; p.clamped = a.clamped; p.tiles_touched = a.tiles_touched;
-    p.block_sums = a.block_sums;
-    const size_t lds = a.shs ? (size_t)256 * (3 * a.M + 1) * 4 : 0;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), lds, s, p, focal_x, focal_y, gx, gy);
+    p.block_sums = a.block_sums; p.features_dc = a.features_dc; p.features_rest = a.features_rest;
+    const size_t lds = (a.shs || a.raw) ? (size_t)256 * (3 * a.M + 1) * 4 : 0;
+    if (a.raw)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, focal_x, focal_y, gx, gy);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, focal_x, focal_y, gx, gy);
 }
 
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,

@@ -96,19 +96,46 @@ def torch_l1_ssim(img, gt, lam):
     return (1.0 - lam) * torch.abs(img - gt).mean() + lam * (1.0 - ssim_map.mean())
 
 
-def full_step_timing(args, rasterizers, params, tensors, H, W, dev):
-    """Context figure (not the headline): render + loss + backward per step, fused HIP loss vs stock torch loss."""
+def full_step_timing(args, rasterizers, g, dL, H, W, dev):
+    """Context figures (not the headline): the training step from GaussianModel's RAW parameters, i.e. including the
+    activations of scene/gaussian_model.py:102-122 and the loss of train.py:116-117, in the reference's data flow (torch
+    activations + rasterizer [+ torch loss]) and with the fused raw-parameter operator [+ fused HIP loss]."""
     from based_on_point_cloud_partitions_amd import loss as hip_loss
+    from based_on_point_cloud_partitions_amd.renderer import rasterize_gaussian_params
 
-    xyz, scales, rots, opac, shs = tensors
+    leaf = lambda t: t.to(dev).contiguous().requires_grad_(True)
+    xyz, f_dc, f_rest = leaf(g.xyz), leaf(g.shs[:, :1]), leaf(g.shs[:, 1:])
+    op_raw, sc_raw = leaf(torch.logit(g.opacities.clamp(1e-6, 1 - 1e-6))), leaf(torch.log(g.scales))
+    rot_raw = leaf(g.rotations * 1.5)
+    params = [xyz, f_dc, f_rest, op_raw, sc_raw, rot_raw]
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def render_reference(r):  # gaussian_renderer/__init__.py:52-93 with the getters of gaussian_model.py:102-122
+        screenspace = torch.zeros_like(xyz, requires_grad=True)
+        image, _ = r(means3D=xyz, means2D=screenspace, opacities=torch.sigmoid(op_raw), shs=torch.cat((f_dc, f_rest), dim=1),
+                     scales=torch.exp(sc_raw), rotations=torch.nn.functional.normalize(rot_raw))
+        return image
+
+    def render_fused(r):
+        screenspace = torch.zeros_like(xyz, requires_grad=True)
+        image, _ = rasterize_gaussian_params(xyz, screenspace, f_dc, f_rest, op_raw, sc_raw, rot_raw, r.raster_settings)
+        return image
+
+    variants = (
+        ("raster_from_raw_params_reference_dataflow", render_reference, None),
+        ("raster_from_raw_params_fused", render_fused, None),
+        ("step_with_loss_reference_dataflow_torch_loss", render_reference, lambda im: torch_l1_ssim(im, gt, 0.2)),
+        ("step_with_loss_reference_dataflow_hip_loss", render_reference, lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)),
+        ("step_with_loss_fused_params_hip_loss", render_fused, lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)),
+    )
     res = {}
-    for name, fn in (("hip_fused_loss", lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)), ("torch_loss", lambda im: torch_l1_ssim(im, gt, 0.2))):
+    for name, render, loss in variants:
         def one(i):
-            r = rasterizers[i % len(rasterizers)]
-            screenspace = torch.zeros_like(xyz, requires_grad=True)
-            image, _ = r(means3D=xyz, means2D=screenspace, opacities=opac, shs=shs, scales=scales, rotations=rots)
-            fn(image).backward()
+            image = render(rasterizers[i % len(rasterizers)])
+            if loss is None:
+                image.backward(dL)
+            else:
+                loss(image).backward()
             for p in params:
                 p.grad = None
         for i in range(4):
@@ -118,8 +145,9 @@ def full_step_timing(args, rasterizers, params, tensors, H, W, dev):
         for i in range(args.steps):
             one(4 + i)
         torch.cuda.synchronize()
-        res[name + "_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
-    res["note"] = "render + (1-0.2)*L1 + 0.2*(1-SSIM) + backward on the same workload; context only, not the headline metric"
+        res[name + "_ms"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
+    res["note"] = ("per-step ms from GaussianModel's raw parameters (exp/sigmoid/normalize/cat included): raster_* = forward + "
+                   "backward with a fixed dL/dcolor; step_with_loss_* add (1-0.2)*L1 + 0.2*(1-SSIM); context only, not the headline")
     return res
 
 
@@ -132,7 +160,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true", help="time the region without per-stage HIP events")
     ap.add_argument("--full-step", action="store_true",
-                    help="also time render + L1/SSIM loss + backward (train.py:107-118), fused HIP loss vs stock torch ops")
+                    help="also time the step from raw parameters (activations fused or not) and with the L1/SSIM loss (train.py:107-118)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -237,7 +265,7 @@ def main():
 
     full = None
     if args.full_step:
-        full = full_step_timing(args, rasterizers, params, (xyz, scales, rots, opac, shs), H, W, dev)
+        full = full_step_timing(args, rasterizers, g, dL, H, W, dev)
 
     if rank == 0:
         used = [stats[(args.warmup + i) % len(stats)] for i in range(args.steps)]

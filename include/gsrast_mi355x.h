@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -80,6 +80,31 @@ int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* back
                  size_t image_bytes, void* scratch, size_t scratch_bytes, const float* dL_dpix, float* dL_dmeans2D,
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                  float* dL_dscales, float* dL_drotations, void* stream);
+
+/* Raw-parameter operator: the rasterizer fed directly with the parameters GaussianModel stores
+ * (scene/gaussian_model.py:48-56) -- xyz [P][3], features_dc [P][1][3], features_rest [P][M-1][3], opacity_raw [P][1],
+ * scaling_raw [P][3], rotation_raw [P][4] -- instead of the activated copies gaussian_renderer/__init__.py:52-93 builds
+ * per render with get_scaling = exp, get_rotation = normalize (x / max(||x||, 1e-12)), get_opacity = sigmoid and
+ * get_features = cat(features_dc, features_rest) (gaussian_model.py:102-122).  Activations are evaluated inside the
+ * per-Gaussian kernels, and the backward returns gradients w.r.t. the RAW parameters (what autograd hands the optimizer
+ * in train.py:155-157), so the four activation passes, the 96 MB concat and their autograd mirrors never run.
+ * gsr_forward_params has gsr_forward's protocol (returns 1 when the binning buffer is too small: allocate and call
+ * gsr_forward_render).  The state buffers are interchangeable with gsr_forward's (gsr_debug_export works on both). */
+int gsr_forward_params(int P, int D, int M, const float* background, const float* xyz, const float* features_dc,
+                       const float* features_rest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
+                       float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H,
+                       float tan_fovx, float tan_fovy, int* radii, void* geom_buffer, size_t geom_bytes, void* binning_buffer,
+                       size_t binning_bytes, void* image_buffer, size_t image_bytes, float* out_color, int64_t* num_rendered_host,
+                       void* stream);
+/* Outputs: dL_dmeans2D[P][3], dL_dxyz[P][3], dL_dfeatures_dc[P][1][3], dL_dfeatures_rest[P][M-1][3] (NULL iff M == 1),
+ * dL_dopacity_raw[P], dL_dscaling_raw[P][3], dL_drotation_raw[P][4]; every element is written. */
+int gsr_backward_params(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* xyz,
+                        const float* features_dc, const float* features_rest, const float* scaling_raw, const float* rotation_raw,
+                        float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                        float tan_fovy, const int* radii, const void* geom_buffer, size_t geom_bytes, const void* binning_buffer,
+                        size_t binning_bytes, const void* image_buffer, size_t image_bytes, void* scratch, size_t scratch_bytes,
+                        const float* dL_dpix, float* dL_dmeans2D, float* dL_dxyz, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
+                        float* dL_dopacity_raw, float* dL_dscaling_raw, float* dL_drotation_raw, void* stream);
 
 /* markVisible (rasterize_points.cu:198-217): present[i] = 1 iff the point passes the near-plane test. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -758,6 +758,60 @@ void orc_preprocess_backward(int P, int D, int M, const float* means3D, const in
     }
 }
 
+/* ------------------------------------------------------------------------
+ * Parameter activations of GaussianModel (/root/reference/scene/gaussian_model.py:33-40,102-122), the inputs
+ * gaussian_renderer/__init__.py:52-93 hands the rasterizer:
+ *   get_scaling = torch.exp(_scaling); get_opacity = torch.sigmoid(_opacity);
+ *   get_rotation = torch.nn.functional.normalize(_rotation) = x / max(||x||_2, 1e-12);
+ *   get_features = torch.cat((_features_dc, _features_rest), dim=1).
+ * Arithmetic contract for the fused raw-parameter operator (gsr_forward_params / gsr_backward_params): exp is gs_expf,
+ * sigmoid(x) = 1 / (1 + gs_expf(-x)), ||q|| = sqrtf(((q0^2 + q1^2) + q2^2) + q3^2).  torch's own exp / sigmoid differ
+ * from these by <= 2 ulp; tests/test_params_operator.py pins this restatement against torch on CPU.
+ * ---------------------------------------------------------------------- */
+void orc_activate(int P, int Mrest, const float* f_dc, const float* f_rest, const float* opacity_raw, const float* scaling_raw,
+                  const float* rotation_raw, float* shs, float* opacities, float* scales, float* rotations)
+{
+    const int M = 1 + Mrest;
+    for (int i = 0; i < P; i++) {
+        for (int c = 0; c < 3; c++) shs[(size_t)i * M * 3 + c] = f_dc[(size_t)i * 3 + c];
+        for (int c = 0; c < 3 * Mrest; c++) shs[(size_t)i * M * 3 + 3 + c] = f_rest[(size_t)i * Mrest * 3 + c];
+        opacities[i] = 1.0f / (1.0f + gs_expf(-opacity_raw[i]));
+        for (int c = 0; c < 3; c++) scales[3 * i + c] = gs_expf(scaling_raw[3 * i + c]);
+        const float* q = rotation_raw + 4 * (size_t)i;
+        const float n = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+        const float d = fmaxf_(n, 1e-12f);
+        for (int c = 0; c < 4; c++) rotations[4 * i + c] = q[c] / d;
+    }
+}
+
+/* autograd of the above (torch: exp' = y, sigmoid' = (1 - y) y, normalize' = (g - q (q.g)) / ||x||, or g / eps when the
+ * norm sits below the clamp; cat' = split) */
+void orc_activate_backward(int P, int Mrest, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw,
+                           const float* dL_dsh, const float* dL_dopacity, const float* dL_dscales, const float* dL_drots,
+                           float* dL_df_dc, float* dL_df_rest, float* dL_dopacity_raw, float* dL_dscaling_raw,
+                           float* dL_drotation_raw)
+{
+    const int M = 1 + Mrest;
+    for (int i = 0; i < P; i++) {
+        for (int c = 0; c < 3; c++) dL_df_dc[(size_t)i * 3 + c] = dL_dsh[(size_t)i * M * 3 + c];
+        for (int c = 0; c < 3 * Mrest; c++) dL_df_rest[(size_t)i * Mrest * 3 + c] = dL_dsh[(size_t)i * M * 3 + 3 + c];
+        const float y = 1.0f / (1.0f + gs_expf(-opacity_raw[i]));
+        dL_dopacity_raw[i] = dL_dopacity[i] * ((1.0f - y) * y);
+        for (int c = 0; c < 3; c++) dL_dscaling_raw[3 * i + c] = dL_dscales[3 * i + c] * gs_expf(scaling_raw[3 * i + c]);
+        const float* v = rotation_raw + 4 * (size_t)i;
+        const float* g = dL_drots + 4 * (size_t)i;
+        const float n = sqrtf(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
+        if (n > 1e-12f) {
+            float q[4];
+            for (int c = 0; c < 4; c++) q[c] = v[c] / n;
+            const float dot = ((q[0] * g[0] + q[1] * g[1]) + q[2] * g[2]) + q[3] * g[3];
+            for (int c = 0; c < 4; c++) dL_drotation_raw[4 * i + c] = (g[c] - q[c] * dot) / n;
+        } else {
+            for (int c = 0; c < 4; c++) dL_drotation_raw[4 * i + c] = g[c] / 1e-12f;
+        }
+    }
+}
+
 /* checkFrustum, rasterizer_impl.cu:54-66 (+ auxiliary.h:139-164) */
 void orc_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
 {

@@ -160,6 +160,45 @@ def backward(st, dL_dpix):
     return g
 
 
+def activate(features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw):
+    """GaussianModel getters (scene/gaussian_model.py:102-122): returns dict(shs, opacities, scales, rotations)."""
+    L = lib()
+    f_dc = np.ascontiguousarray(np.asarray(features_dc, np.float32))
+    P = f_dc.reshape(-1, 3).shape[0]
+    f_rest = np.ascontiguousarray(np.asarray(features_rest, np.float32)).reshape(P, -1, 3)
+    Mrest = f_rest.shape[1]
+    o = np.ascontiguousarray(np.asarray(opacity_raw, np.float32)).reshape(P, 1)
+    sc = np.ascontiguousarray(np.asarray(scaling_raw, np.float32)).reshape(P, 3)
+    rot = np.ascontiguousarray(np.asarray(rotation_raw, np.float32)).reshape(P, 4)
+    out = dict(shs=np.zeros((P, 1 + Mrest, 3), np.float32), opacities=np.zeros((P, 1), np.float32),
+               scales=np.zeros((P, 3), np.float32), rotations=np.zeros((P, 4), np.float32))
+    if P:
+        L.orc_activate(ctypes.c_int(P), ctypes.c_int(Mrest), _p(f_dc, _f), _p(f_rest if Mrest else None, _f), _p(o, _f),
+                       _p(sc, _f), _p(rot, _f), _p(out["shs"], _f), _p(out["opacities"], _f), _p(out["scales"], _f),
+                       _p(out["rotations"], _f))
+    return out
+
+
+def activate_backward(opacity_raw, scaling_raw, rotation_raw, g):
+    """Chain rule through activate() for the gradient dict `g` of backward(): gradients w.r.t. the raw parameters."""
+    L = lib()
+    P, M = g["dL_dsh"].shape[0], g["dL_dsh"].shape[1]
+    Mrest = M - 1
+    o = np.ascontiguousarray(np.asarray(opacity_raw, np.float32)).reshape(P, 1)
+    sc = np.ascontiguousarray(np.asarray(scaling_raw, np.float32)).reshape(P, 3)
+    rot = np.ascontiguousarray(np.asarray(rotation_raw, np.float32)).reshape(P, 4)
+    out = dict(dL_dfeatures_dc=np.zeros((P, 1, 3), np.float32), dL_dfeatures_rest=np.zeros((P, Mrest, 3), np.float32),
+               dL_dopacity_raw=np.zeros((P, 1), np.float32), dL_dscaling_raw=np.zeros((P, 3), np.float32),
+               dL_drotation_raw=np.zeros((P, 4), np.float32), dL_dxyz=g["dL_dmeans3D"], dL_dmeans2D=g["dL_dmeans2D"])
+    if P:
+        L.orc_activate_backward(ctypes.c_int(P), ctypes.c_int(Mrest), _p(o, _f), _p(sc, _f), _p(rot, _f),
+                                _p(np.ascontiguousarray(g["dL_dsh"]), _f), _p(np.ascontiguousarray(g["dL_dopacity"]), _f),
+                                _p(np.ascontiguousarray(g["dL_dscales"]), _f), _p(np.ascontiguousarray(g["dL_drotations"]), _f),
+                                _p(out["dL_dfeatures_dc"], _f), _p(out["dL_dfeatures_rest"] if Mrest else None, _f),
+                                _p(out["dL_dopacity_raw"], _f), _p(out["dL_dscaling_raw"], _f), _p(out["dL_drotation_raw"], _f))
+    return out
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     L = lib()
     means3D = _f32(means3D)
