@@ -228,7 +228,7 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
             }
             StageTimer t(GSR_STAGE_SORT, s);
             gsr_launch_tile_binning(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
-                                    (uint32_t*)(b + B.starts), ranges, ka, va, kb, s);
+                                    (uint32_t*)(b + B.starts), (uint32_t*)(b + B.order), ranges, ka, va, kb, s);
             point_list = va;
         } else {
         {
@@ -253,10 +253,9 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
     }
     {
         StageTimer t(GSR_STAGE_RENDER_FWD, s);
-        uint8_t* flags = R > 0 ? (uint8_t*)(b + B.flags) : nullptr;
-        if (flags && gsr_variant("FLAGS", 0)) hipMemsetAsync(flags, 0, (size_t)R, s);
+        const uint32_t* order = (R > 0 && gsr_variant("BIN", 1)) ? (const uint32_t*)(b + B.order) : nullptr;
         gsr_launch_render_forward(W, H, ranges, point_list, (const float*)(g + G.splat), background, (float*)(im + I.final_T),
-                                  (uint32_t*)(im + I.n_contrib), out_color, flags, s);
+                                  (uint32_t*)(im + I.n_contrib), out_color, order, s);
     }
     return check_hip("forward_render");
 }
@@ -334,7 +333,7 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
         StageTimer t(GSR_STAGE_RENDER_BWD, s);
         gsr_launch_render_backward(W, H, (const uint32_t*)(im + I.ranges), point_list, (const float*)(g + G.splat), background,
                                    (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
-                                   (const uint8_t*)(b + B.flags), (float*)scratch, s);
+                                   gsr_variant("BIN", 1) ? (const uint32_t*)(b + B.order) : nullptr, (float*)scratch, s);
     }
     a.cov3D_in = cov3D_precomp ? cov3D_precomp : (const float*)(g + G.cov3D);
     a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);

@@ -101,12 +101,36 @@ __global__ void __launch_bounds__(256) tile_colscan_kernel(int T, int nslices, u
 }
 
 // (3) exclusive scan of the tile totals (single workgroup) -> starts[] and the reference's ranges[] (uint2 per tile).
+// Also emits order[]: the tile ids by descending list length (256 length classes, counting sort).  The blend kernels
+// take workgroup b -> tile order[b], so the long lists start first and the short ones fill the tail of the launch
+// (longest-processing-time-first); which tile a workgroup renders has no effect on any result.
 __global__ void __launch_bounds__(1024) tile_starts_kernel(int T, const uint32_t* __restrict__ totals, uint32_t* __restrict__ starts,
-                                                           uint32_t* __restrict__ ranges)
+                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
+    __shared__ uint32_t cls_cnt[256];
     if (threadIdx.x == 0) carry_s = 0;
+    if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // length class: 8 entries per class up to 2040, everything longer in the top class
+    for (int i = threadIdx.x; i < T; i += 1024) atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan from the top class down (one wave, 4 classes per lane)
+        const int c0 = 255 - 4 * (int)threadIdx.x;
+        const uint32_t n0 = cls_cnt[c0], n1 = cls_cnt[c0 - 1], n2 = cls_cnt[c0 - 2], n3 = cls_cnt[c0 - 3];
+        const uint32_t tsum = n0 + n1 + n2 + n3;
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += u;
+        }
+        const uint32_t b = incl - tsum;
+        cls_cnt[c0] = b; cls_cnt[c0 - 1] = b + n0; cls_cnt[c0 - 2] = b + n0 + n1; cls_cnt[c0 - 3] = b + n0 + n1 + n2;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 1024) order[atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u)] = (uint32_t)i;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int EPT = 8;  // tiles per thread and iteration: 1080p (8,160 tiles) is a single iteration
@@ -410,7 +434,8 @@ int gsr_tile_slices(int P, int* gpb_out)
 }
 
 void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* starts,
-                             uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted, hipStream_t s)
+                             uint32_t* order, uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
+                             hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int T = gx * gy;
@@ -419,7 +444,7 @@ void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* 
     const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
     hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table);
     hipLaunchKernelGGL(tile_colscan_kernel, dim3((T + 31) / 32), dim3(256), 0, s, T, ns, table, totals);
-    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(1024), 0, s, T, totals, starts, ranges);
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(1024), 0, s, T, totals, starts, ranges, order);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table, starts,
                        reinterpret_cast<uint2*>(bins));
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<const unsigned long long*>(bins),

@@ -29,7 +29,7 @@ struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
 };
 struct BinLayout {
-    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, flags, table, totals, starts, bytes;
+    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, flags, table, totals, starts, order, bytes;
     uint32_t sort_blocks;
 };
 
@@ -92,6 +92,7 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
         L.table = o; o = gsr_align(o + ns * t * 4);
         L.totals = o; o = gsr_align(o + t * 4);
         L.starts = o; o = gsr_align(o + t * 4);
+        L.order = o; o = gsr_align(o + t * 4);  // tiles by descending list length: launch order of the blend kernels
     }
     L.bytes = o;
     return L;
@@ -133,14 +134,15 @@ int gsr_launch_radix_sort(uint64_t* ka, uint64_t* kb, uint32_t* va, uint32_t* vb
                           uint32_t* hist_global, uint32_t* hist_blocks, uint32_t nblocks, hipStream_t s);
 static inline int gsr_sort_result_in_b(int end_bit) { return (((end_bit + 7) / 8) & 1); }
 void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* starts,
-                             uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted, hipStream_t s);
+                             uint32_t* order, uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
+                             hipStream_t s);
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
-                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, uint8_t* flags,
+                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
                                hipStream_t s);
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                                const uint8_t* flags, float* grad_rows, hipStream_t s);
+                                const uint32_t* order, float* grad_rows, hipStream_t s);
 int gsr_variant(const char* name, int dflt);  // experiment switch read from the environment (GSR_<name>)
 struct GaussBackwardArgs {
     int P, D, M, W, H;

@@ -15,7 +15,7 @@
 // once per list entry after the reduction instead of once per pixel.
 //
 // Traversal is back to front from the tile's largest n_contrib (entries behind it contribute to no pixel,
-// backward.cu:480-482); alpha / G are recomputed with exactly the forward's arithmetic.
+// backward.cu:480-482); alpha / G are recomputed so that the set of blended pairs is exactly the forward's (see FAST_EXP).
 // The kernel is VALU-issue bound; see DESIGN.md §4 for the instruction budget.
 #include "common.h"
 
@@ -108,8 +108,9 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
 
 constexpr int NV = 9;  // partial sums per list entry
 
-template <int BATCH, bool RS>
-__global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ ranges,
+template <int BATCH, bool RS, bool FAST_EXP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) render_backward_kernel(int W, int H, int gx, int gy, int wave8x8, const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ ranges,
                                                               const uint32_t* __restrict__ point_list,
                                                               const float* __restrict__ splat, const float* __restrict__ bg,
                                                               const float* __restrict__ final_Ts,
@@ -124,14 +125,19 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
     __shared__ __attribute__((aligned(16))) float s_acc[4 * ACC_STRIDE];
     __shared__ uint32_t s_max[4];
 
-    const uint32_t tile = blockIdx.y * gx + blockIdx.x;
+    // 1-D launch in `order` (tiles by descending list length, binning.hip); NULL = row-major
+    const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;
+    const uint32_t bx = tile % (uint32_t)gx, by = tile / (uint32_t)gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t pix_x = blockIdx.x * GSR_TILE_X + (tid & 15), pix_y = blockIdx.y * GSR_TILE_Y + (tid >> 4);
+    // pixel of this lane: each wave owns an 8x8 block of the tile (wave8x8) or a 16x4 strip
+    const uint32_t in_x = wave8x8 ? ((tid >> 6) & 1) * 8 + (tid & 7) : (tid & 15);
+    const uint32_t in_y = wave8x8 ? (tid >> 7) * 8 + ((tid >> 3) & 7) : (tid >> 4);
+    const uint32_t pix_x = bx * GSR_TILE_X + in_x, pix_y = by * GSR_TILE_Y + in_y;
     const bool inside = pix_x < (uint32_t)W && pix_y < (uint32_t)H;
     const size_t pix_id = (size_t)W * pix_y + pix_x;
     const size_t plane = (size_t)H * W;
     const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
-    const float tile_x0 = (float)(blockIdx.x * GSR_TILE_X), tile_y0 = (float)(blockIdx.y * GSR_TILE_Y);
+    const float tile_x0 = (float)(bx * GSR_TILE_X), tile_y0 = (float)(by * GSR_TILE_Y);
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
     const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const uint32_t total = r1 - r0;
@@ -177,7 +183,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
             uint32_t mnx, mny, mxx, mxy;
             gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
-            row = __float_as_uint(q2.w) + (blockIdx.y - mny) * (mxx - mnx) + (blockIdx.x - mnx);
+            row = __float_as_uint(q2.w) + (by - mny) * (mxx - mnx) + (bx - mnx);
             pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
             keep = !gsr_tile_cannot_touch(q0.x, q0.y, q0.z, q0.w, q1.x, pthr, tile_x0, tile_y0);
             if (!keep) {
@@ -220,8 +226,16 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
             const bool maybe = __builtin_amdgcn_fmed3f(power, b.z, 0.0f) == power;
             if (__ballot(maybe) == 0ull) continue;  // wave-uniform
             bool contrib = maybe && kidx < last_contributor && power <= 0.0f;
-            const float G = gsr_expf(power);
-            const float alpha = fminf(0.99f, b.y * G);
+            // G = exp(power) from the hardware exp2 (v_exp_f32, <= 1e-6 relative off gsr_expf on the range that can pass),
+            // 2 issue slots instead of the 17 instructions of the forward's fully specified gsr_expf.  The alpha >= 1/255
+            // decision must be the forward's: when any lane's alpha lies within 8e-6 (relative) of the threshold the wave
+            // redoes this entry with gsr_expf, so the set of blended pairs is exactly the forward's.
+            float G = FAST_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gsr_expf(power);
+            float alpha = fminf(0.99f, b.y * G);
+            if (FAST_EXP && __ballot(contrib && fabsf(__builtin_fmaf(alpha, 255.0f, -1.0f)) < 8e-6f) != 0ull) {
+                G = gsr_expf(power);
+                alpha = fminf(0.99f, b.y * G);
+            }
             contrib = contrib && alpha >= 1.0f / 255.0f;
             if (__ballot(contrib) == 0ull) continue;  // wave-uniform
             // From here all 64 lanes run the same straight-line code.  A lane that does not contribute is given alpha = G = 0:
@@ -289,7 +303,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
         const float4 q0 = rec[0], q2 = rec[2];
         uint32_t mnx, mny, mxx, mxy;
         gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
-        const uint32_t row = __float_as_uint(q2.w) + (blockIdx.y - mny) * (mxx - mnx) + (blockIdx.x - mnx);
+        const uint32_t row = __float_as_uint(q2.w) + (by - mny) * (mxx - mnx) + (bx - mnx);
         float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         o[0] = z; o[1] = z; o[2] = z;
@@ -300,16 +314,19 @@ __global__ void __launch_bounds__(256) render_backward_kernel(int W, int H, int 
 
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                                const uint8_t* flags, float* grad_rows, hipStream_t s)
+                                const uint32_t* order, float* grad_rows, hipStream_t s)
 {
-    (void)flags;
+    if (!gsr_variant("LPT", 1)) order = nullptr;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-    const int batch = gsr_variant("BWD_BATCH", 128), rs = gsr_variant("BWD_RS", 1);
-#define GSR_BWD_LAUNCH(B, R_)                                                                                                   \
-    hipLaunchKernelGGL((render_backward_kernel<B, R_>), dim3(gx, gy), dim3(256), 0, s, W, H, gx, gy, ranges, point_list, splat, \
+    const int batch = gsr_variant("BWD_BATCH", 128), rs = gsr_variant("BWD_RS", 1), wave8x8 = gsr_variant("WAVE8X8", 1);
+#define GSR_BWD_LAUNCH(B, R_, F_)                                                                                               \
+    hipLaunchKernelGGL((render_backward_kernel<B, R_, F_>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, \
                        bg, final_T, n_contrib, dL_dpix, grad_rows)
-    if (batch == 256) { if (rs) GSR_BWD_LAUNCH(256, true); else GSR_BWD_LAUNCH(256, false); }
-    else if (batch == 64) { if (rs) GSR_BWD_LAUNCH(64, true); else GSR_BWD_LAUNCH(64, false); }
-    else { if (rs) GSR_BWD_LAUNCH(128, true); else GSR_BWD_LAUNCH(128, false); }
+    const int fast = gsr_variant("BWD_FASTEXP", 1);
+    if (batch == 256) GSR_BWD_LAUNCH(256, true, true);
+    else if (batch == 64) GSR_BWD_LAUNCH(64, true, true);
+    else if (!rs) GSR_BWD_LAUNCH(128, false, false);
+    else if (fast) GSR_BWD_LAUNCH(128, true, true);
+    else GSR_BWD_LAUNCH(128, true, false);
 #undef GSR_BWD_LAUNCH
 }

@@ -14,7 +14,8 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, const uint32_t* __restrict__ ranges,
+__global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, int wave8x8, const uint32_t* __restrict__ order,
+                                                             const uint32_t* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list,
                                                              const float* __restrict__ splat, const float* __restrict__ bg,
                                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -26,10 +27,15 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     __shared__ int s_done[4];
     __shared__ int s_wcnt[4];    // entries each wave keeps after the tile-level rejection
 
-    const uint32_t tile = blockIdx.y * gx + blockIdx.x;
+    // 1-D launch in `order` (tiles by descending list length, binning.hip); NULL = row-major
+    const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;
+    const uint32_t bx = tile % (uint32_t)gx, by = tile / (uint32_t)gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const float tile_x0 = (float)(blockIdx.x * GSR_TILE_X), tile_y0 = (float)(blockIdx.y * GSR_TILE_Y);
-    const uint32_t pix_x = blockIdx.x * GSR_TILE_X + (tid & 15), pix_y = blockIdx.y * GSR_TILE_Y + (tid >> 4);
+    const float tile_x0 = (float)(bx * GSR_TILE_X), tile_y0 = (float)(by * GSR_TILE_Y);
+    // pixel of this lane: each wave owns an 8x8 block of the tile (wave8x8) or a 16x4 strip
+    const uint32_t in_x = wave8x8 ? ((tid >> 6) & 1) * 8 + (tid & 7) : (tid & 15);
+    const uint32_t in_y = wave8x8 ? (tid >> 7) * 8 + ((tid >> 3) & 7) : (tid >> 4);
+    const uint32_t pix_x = bx * GSR_TILE_X + in_x, pix_y = by * GSR_TILE_Y + in_y;
     const bool inside = pix_x < (uint32_t)W && pix_y < (uint32_t)H;
     const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
     // tile range is workgroup-uniform: keep it (and every loop bound derived from it) in scalar registers
@@ -130,11 +136,11 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
 }  // namespace
 
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
-                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, uint8_t* flags,
+                               const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
                                hipStream_t s)
 {
-    (void)flags;
+    if (!gsr_variant("LPT", 1)) order = nullptr;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-    hipLaunchKernelGGL(render_forward_kernel, dim3(gx, gy), dim3(256), 0, s, W, H, gx, ranges, point_list, splat, bg, final_T,
+    hipLaunchKernelGGL(render_forward_kernel, dim3(gx * gy), dim3(256), 0, s, W, H, gx, gsr_variant("WAVE8X8", 1), order, ranges, point_list, splat, bg, final_T,
                        n_contrib, out_color);
 }
