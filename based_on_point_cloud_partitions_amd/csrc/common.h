@@ -191,6 +191,26 @@ __device__ __forceinline__ float gsr_expf(float x)
     return x < -80.0f ? 0.0f : e;
 }
 
+// gsr_expf for arguments known to lie in [-80, 80] (the blend kernels: pthr >= -80 is enforced when a list entry is staged and
+// power <= 0 is tested before): the range handling of gsr_expf is dead there, the value is bit-identical.
+__device__ __forceinline__ float gsr_expf_inrange(float x)
+{
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    return __int_as_float(__float_as_int(y) + (int)n * (1 << 23));
+}
+// Wave-uniform "any lane" test.  __ballot() != 0 compiles to v_cndmask + v_cmp_ne on top of the compare that produced the
+// predicate (two half-rate VALU instructions); the ballot intrinsic folds into a scalar test of the compare's own lane mask.
+__device__ __forceinline__ bool gsr_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 // Moves the workgroup's [rows][3M] tile between global memory and LDS (row stride `stride` floats in LDS).
 __device__ __forceinline__ void sh_tile_load(const float* __restrict__ g, float* __restrict__ s, int rows, int n3, int stride)
 {

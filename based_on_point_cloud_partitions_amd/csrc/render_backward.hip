@@ -100,9 +100,18 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "=&v"(t0), "=&v"(t1),
           "=&v"(t2), "=&v"(t3)
         : "s"(m0), "s"(m1), "s"(m2), "s"(m8));
-    // levels 5, 6: lane-wise across the four rows
-    v0 += __shfl_xor(v0, 16, 64);
-    v0 += __shfl_xor(v0, 32, 64);
+    // levels 5, 6: lane-wise across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap (two VALU
+    // instructions per level; __shfl_xor would take two dependent trips through the LDS crossbar)
+    {
+        const uint32_t u = __float_as_uint(v0);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // (row0,row0,row2,row2), (row1,row1,row3,row3)
+        v0 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const uint32_t u = __float_as_uint(v0);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // (lo,lo), (hi,hi)
+        v0 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     return v0;
 }
 
@@ -162,6 +171,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
 
     float accum0 = 0.f, accum1 = 0.f, accum2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     float* my_acc = s_acc + wave * ACC_STRIDE;
+    const float parked_x = 1e30f;
     const int rounds = (int)((hi + BATCH - 1) / BATCH);
     // reduce-scatter constants: lane masks and the accumulator slot this lane writes
     const unsigned long long M0 = 0xAAAAAAAAAAAAAAAAull, M1 = 0xCCCCCCCCCCCCCCCCull, M2 = 0xF0F0F0F0F0F0F0F0ull,
@@ -201,7 +211,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
         if (keep) {  // order-preserving compaction
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
             s_a[pos] = q0;
-            s_b[pos] = make_float4(q1.x, q1.y, pthr, __uint_as_float(k));
+            s_b[pos] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float(k));  // clamp: see the forward
             s_c[pos] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(row));
         }
         {   // zero this wave's accumulators
@@ -218,32 +228,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
             const uint32_t kidx = __float_as_uint(b.w);  // position of this entry in the tile's list
             // entries behind this pixel's last contributor are parked far away (power -> -inf / NaN), so one range test
             // covers `kidx < last_contributor`, `power <= 0` and the conservative alpha < 1/255 shortcut
-            const float px = kidx < last_contributor ? pixf_x : 1e30f;
+            const unsigned long long m_act = __builtin_amdgcn_ballot_w64(kidx < last_contributor);
+            float px;
+            // s_nop 1: the mask was just written by a VALU compare (2 wait states before a VALU reads it as an operand;
+            // the compiler pads its own selects the same way but does not look inside asm)
+            asm("s_nop 1\n v_cndmask_b32 %0, %1, %2, %3" : "=v"(px) : "v"(parked_x), "v"(pixf_x), "s"(m_act));
             const float dx = a.x - px, dy = a.y - pixf_y;
             // identical to the forward (CONTRACT-FMA)
             const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
             const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
-            const bool maybe = __builtin_amdgcn_fmed3f(power, b.z, 0.0f) == power;
-            if (__ballot(maybe) == 0ull) continue;  // wave-uniform
-            bool contrib = maybe && kidx < last_contributor && power <= 0.0f;
+            // Lane predicates are kept as 64-bit lane masks in scalar registers (each ballot of a plain compare IS the
+            // compare's result mask): combining them and testing "any lane" is scalar work, and the two selects below take
+            // the mask directly.  Written with bools, the compiler re-materialises every combined predicate through
+            // v_cndmask + v_cmp_ne (two half-rate VALU instructions per test).
+            const unsigned long long m_maybe = __builtin_amdgcn_ballot_w64(power >= b.z);  // power > 0 is tested below
+            if (m_maybe == 0ull) continue;  // wave-uniform
+            unsigned long long m_c = m_maybe & m_act & __builtin_amdgcn_ballot_w64(power <= 0.0f);
             // G = exp(power) from the hardware exp2 (v_exp_f32, <= 1e-6 relative off gsr_expf on the range that can pass),
             // 2 issue slots instead of the 17 instructions of the forward's fully specified gsr_expf.  The alpha >= 1/255
             // decision must be the forward's: when any lane's alpha lies within 8e-6 (relative) of the threshold the wave
             // redoes this entry with gsr_expf, so the set of blended pairs is exactly the forward's.
-            float G = FAST_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gsr_expf(power);
+            float G = FAST_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gsr_expf_inrange(power);
             float alpha = fminf(0.99f, b.y * G);
-            if (FAST_EXP && __ballot(contrib && fabsf(__builtin_fmaf(alpha, 255.0f, -1.0f)) < 8e-6f) != 0ull) {
-                G = gsr_expf(power);
+            if (FAST_EXP && (m_c & __builtin_amdgcn_ballot_w64(fabsf(alpha - 1.0f / 255.0f) < 3e-8f)) != 0ull) {
+                G = gsr_expf_inrange(power);
                 alpha = fminf(0.99f, b.y * G);
             }
-            contrib = contrib && alpha >= 1.0f / 255.0f;
-            if (__ballot(contrib) == 0ull) continue;  // wave-uniform
+            m_c &= __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
+            if (m_c == 0ull) continue;  // wave-uniform
             // From here all 64 lanes run the same straight-line code.  A lane that does not contribute is given alpha = G = 0:
             // then T/(1-0) = T, its gradient terms vanish, and the colour recurrence (backward.cu:515) folds the pending
             // (last_alpha, last_color) into accum exactly once -- the same value the next real contributor would have
             // computed -- so no per-variable select is needed.
-            const float Ge = contrib ? G : 0.f;
-            const float ae = contrib ? alpha : 0.f;
+            float Ge, ae;
+            asm("v_cndmask_b32 %0, 0, %2, %4\n v_cndmask_b32 %1, 0, %3, %4" : "=&v"(Ge), "=v"(ae) : "v"(G), "v"(alpha), "s"(m_c));
             const float4 c = s_c[j];
             const float inv = __builtin_amdgcn_rcpf(1.f - ae);
             T = T * inv;  // T / (1 - alpha), backward.cu:502

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     // -inf/NaN so the single range test of the hot loop rejects it -- no `done` mask, no EXEC branch per entry.
     constexpr float PARKED = 1e30f;
     float px = inside ? pixf_x : PARKED;
-    bool wave_done = __ballot(px != PARKED) == 0ull;
+    bool wave_done = !gsr_any(px != PARKED);
 
     for (int i = 0; i < rounds; i++) {
         // gather this batch's records and decide, per entry, whether the tile can see it at all
@@ -77,7 +77,9 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
         if (keep) {  // order-preserving compaction (the walk must stay front to back)
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
             s_a[pos] = q0;
-            s_b[pos] = make_float4(q1.x, q1.y, pthr, __uint_as_float((uint32_t)progress));
+            // walk threshold clamped to -80: below it alpha < op * e^-80, which no opacity turns into 1/255, and the blend's
+            // exp then never sees an argument outside [-80, 0]
+            s_b[pos] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress));
             s_c[pos] = make_float4(q1.z, q1.w, q2.x, 0.f);
         }
         if (tid < 4) {  // padding entries that can never pass the range test (walk runs in groups of 4, no bounds checks)
@@ -96,11 +98,12 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                     // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
                     const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
                     const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
-                    // pthr <= power <= 0  <=>  med3(power, pthr, 0) == power  (superset when pthr > 0; the exact path re-tests)
-                    const bool maybe = __builtin_amdgcn_fmed3f(power, b.z, 0.0f) == power;
-                    if (__ballot(maybe) != 0ull) {  // wave-uniform; rare relative to the skip
+                    // one compare (parked pixels and padding entries give -inf / NaN / pthr = inf and fail it); power > 0 is
+                    // left to the exact path
+                    const bool maybe = power >= b.z;
+                    if (gsr_any(maybe)) {  // wave-uniform; rare relative to the skip
                         if (maybe && px != PARKED && power <= 0.0f) {
-                            const float alpha = fminf(0.99f, b.y * gsr_expf(power));
+                            const float alpha = fminf(0.99f, b.y * gsr_expf_inrange(power));
                             if (alpha >= 1.0f / 255.0f) {
                                 const float test_T = T * (1.0f - alpha);
                                 if (test_T < 0.0001f) {
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                         }
                     }
                 }
-                if (__ballot(px != PARKED) == 0ull) { wave_done = true; break; }
+                if (!gsr_any(px != PARKED)) { wave_done = true; break; }
             }
         }
     }
