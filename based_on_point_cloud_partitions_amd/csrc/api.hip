@@ -102,6 +102,17 @@ bool mailbox_wait(const unsigned long long* host_slot, uint32_t seq, uint32_t* v
     return false;
 }
 
+// Sorted 64-bit keys of the tile-binning path, rebuilt on demand for inspection: (tile << 32) | depth bits of each list entry
+// (the production path keeps only point_list + ranges; the reference's keys are a function of those and the depths).
+__global__ void __launch_bounds__(256) export_keys_kernel(const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                                                          const float* __restrict__ splat, unsigned long long* __restrict__ keys)
+{
+    const uint32_t tile = blockIdx.x;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    for (uint32_t i = r0 + threadIdx.x; i < r1; i += 256)
+        keys[i] = ((unsigned long long)tile << 32) | __float_as_uint(splat[(size_t)point_list[i] * GSR_SPLAT_F + SP_DEPTH]);
+}
+
 __global__ void __launch_bounds__(256) export_geom_kernel(int P, const float* __restrict__ splat, float* means2D, float* depths,
                                                           float* conic_opacity, float* rgb)
 {
@@ -228,7 +239,8 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
             }
             StageTimer t(GSR_STAGE_SORT, s);
             gsr_launch_tile_binning(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
-                                    (uint32_t*)(b + B.starts), (uint32_t*)(b + B.order), ranges, ka, va, kb, s);
+                                    (uint32_t*)(b + B.order), ranges, ka, va,
+                                    gsr_variant("KEYS", 0) ? kb : nullptr, s);
             point_list = va;
         } else {
         {
@@ -481,7 +493,11 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));
         const int bin = gsr_variant("BIN", 1);
         const int in_b = bin ? 0 : gsr_sort_result_in_b(end_bit);
-        if (keys_sorted) hipMemcpyAsync(keys_sorted, b + ((in_b || bin) ? B.keys_b : B.keys_a), (size_t)R * 8, hipMemcpyDeviceToDevice, s);
+        if (keys_sorted && bin && im && g)
+            hipLaunchKernelGGL(export_keys_kernel, dim3(gx * gy), dim3(256), 0, s, (const uint32_t*)(im + I.ranges),
+                               (const uint32_t*)(b + B.vals_a), (const float*)(g + G.splat), (unsigned long long*)keys_sorted);
+        else if (keys_sorted)
+            hipMemcpyAsync(keys_sorted, b + (in_b ? B.keys_b : B.keys_a), (size_t)R * 8, hipMemcpyDeviceToDevice, s);
         if (point_list) hipMemcpyAsync(point_list, b + (in_b ? B.vals_b : B.vals_a), (size_t)R * 4, hipMemcpyDeviceToDevice, s);
     }
     if (im) {

@@ -7,10 +7,10 @@
 //   1. tile_count:   each workgroup takes a slice of the Gaussians and histograms the tiles of their rectangles in LDS
 //                    (one LDS atomic per instance), then stores its row of the [workgroup][tile] table;
 //   2. tile_colscan: per tile, exclusive prefix over the workgroups (in place) + the tile's total;
-//   3. tile_starts:  exclusive scan of the totals -> tile ranges (the reference's `ranges`, empty tiles stay (0,0));
-//   4. tile_scatter: same slicing as (1); an LDS cursor per tile hands out slots, (depth bits, id) pairs go straight
-//                    into their tile's segment (8 B/instance, written once);
-//   5. tile_sort:    one workgroup per tile sorts its segment by (depth, id) in LDS -- bucket sort + insertion sort for
+//   3. tile_scatter: same slicing as (1); every workgroup scans the totals into tile starts (workgroup 0 stores them as the
+//                    reference's `ranges`), then an LDS cursor per tile hands out slots and the (depth bits, id) pairs go
+//                    straight into their tile's segment (8 B/instance, written once);
+//   4. tile_sort:    one workgroup per tile sorts its segment by (depth, id) in LDS -- bucket sort + insertion sort for
 //                    lists up to 1024 entries, a normalized bitonic network (all comparators ascending, tail padded
 //                    virtually) for longer ones -- and writes point_list (+ keys).
 // The order in which (4) fills a segment is arbitrary (LDS atomics), but ids are unique within a tile, so the sorted
@@ -100,84 +100,82 @@ __global__ void __launch_bounds__(256) tile_colscan_kernel(int T, int nslices, u
     }
 }
 
-// (3) exclusive scan of the tile totals (single workgroup) -> starts[] and the reference's ranges[] (uint2 per tile).
-// Also emits order[]: the tile ids by descending list length (256 length classes, counting sort).  The blend kernels
-// take workgroup b -> tile order[b], so the long lists start first and the short ones fill the tail of the launch
-// (longest-processing-time-first); which tile a workgroup renders has no effect on any result.
-__global__ void __launch_bounds__(1024) tile_starts_kernel(int T, const uint32_t* __restrict__ totals, uint32_t* __restrict__ starts,
-                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ order)
-{
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s;
-    __shared__ uint32_t cls_cnt[256];
-    if (threadIdx.x == 0) carry_s = 0;
-    if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    // length class: 8 entries per class up to 2040, everything longer in the top class
-    for (int i = threadIdx.x; i < T; i += 1024) atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u);
-    __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive scan from the top class down (one wave, 4 classes per lane)
-        const int c0 = 255 - 4 * (int)threadIdx.x;
-        const uint32_t n0 = cls_cnt[c0], n1 = cls_cnt[c0 - 1], n2 = cls_cnt[c0 - 2], n3 = cls_cnt[c0 - 3];
-        const uint32_t tsum = n0 + n1 + n2 + n3;
-        uint32_t incl = tsum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off, 64);
-            if ((int)threadIdx.x >= off) incl += u;
-        }
-        const uint32_t b = incl - tsum;
-        cls_cnt[c0] = b; cls_cnt[c0 - 1] = b + n0; cls_cnt[c0 - 2] = b + n0 + n1; cls_cnt[c0 - 3] = b + n0 + n1 + n2;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < T; i += 1024) order[atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u)] = (uint32_t)i;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int EPT = 8;  // tiles per thread and iteration: 1080p (8,160 tiles) is a single iteration
-    for (int base = 0; base < T; base += 1024 * EPT) {
-        const int i0 = base + threadIdx.x * EPT;
-        uint32_t v[EPT], tsum = 0;
-#pragma unroll
-        for (int e = 0; e < EPT; e++) { v[e] = i0 + e < T ? totals[i0 + e] : 0u; tsum += v[e]; }
-        uint32_t incl = tsum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += u;
-        }
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        uint32_t wbase = 0;
-        for (int w = 0; w < wave; w++) wbase += wtot[w];
-        const uint32_t carry = carry_s;
-        uint32_t s = carry + wbase + incl - tsum;
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const int i = i0 + e;
-            if (i < T) {
-                starts[i] = s;
-                ranges[2 * i] = v[e] ? s : 0u;          // identifyTileRanges leaves empty tiles at (0,0) after the memset
-                ranges[2 * i + 1] = v[e] ? s + v[e] : 0u;
-            }
-            s += v[e];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
-        __syncthreads();
-    }
-}
-
-// (4) scatter (depth bits, id) into the tile segments.  Same slicing and LDS size as (1).
+// (3)+(4) scatter (depth bits, id) into the tile segments.  Same slicing and LDS size as (1).
+// Every workgroup first turns the tile totals into the tiles' start offsets itself (an exclusive scan of T numbers costs a
+// 1024-thread workgroup about a microsecond; a separate single-workgroup kernel for it was 11 us of serialised latency on the
+// critical path).  Workgroup 0 also stores the reference's ranges[] (uint2 per tile; empty tiles stay (0,0) like
+// identifyTileRanges after its memset); workgroup 1 also emits order[], the tile ids by descending list length (256 length
+// classes, counting sort): the blend kernels take workgroup b -> tile order[b], so the long lists start first and the
+// short ones fill the tail of the launch (longest-processing-time-first).  Which tile a workgroup renders has no effect
+// on any result.
 __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
-                                                           const uint32_t* __restrict__ table, const uint32_t* __restrict__ starts,
+                                                           const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
+                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
                                                            uint2* __restrict__ bins)
 {
     extern __shared__ uint32_t s_cur[];
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t cls_cnt[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == (gridDim.x > 1 ? 1u : 0u)) {
+        if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        // length class: 8 entries per class up to 2040, everything longer in the top class
+        for (int i = threadIdx.x; i < T; i += SLICE_THREADS) atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) {  // exclusive scan from the top class down (one wave, 4 classes per lane)
+            const int c0 = 255 - 4 * (int)threadIdx.x;
+            const uint32_t n0 = cls_cnt[c0], n1 = cls_cnt[c0 - 1], n2 = cls_cnt[c0 - 2], n3 = cls_cnt[c0 - 3];
+            const uint32_t tsum = n0 + n1 + n2 + n3;
+            uint32_t incl = tsum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(incl, off, 64);
+                if ((int)threadIdx.x >= off) incl += u;
+            }
+            const uint32_t b = incl - tsum;
+            cls_cnt[c0] = b; cls_cnt[c0 - 1] = b + n0; cls_cnt[c0 - 2] = b + n0 + n1; cls_cnt[c0 - 3] = b + n0 + n1 + n2;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += SLICE_THREADS) order[atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u)] = (uint32_t)i;
+    }
     const int first = blockIdx.x * gpb, last = min(P, first + gpb);
+    uint32_t chunk_base = 0;  // instances in the tiles before this chunk
+    constexpr int EPT = TCHUNK / SLICE_THREADS;  // tiles per thread in the scan
     for (int tbase = 0; tbase < T; tbase += TCHUNK) {
         const int tn = min(TCHUNK, T - tbase);
         const uint32_t* row = table + (size_t)blockIdx.x * T + tbase;
-        for (int t = threadIdx.x; t < tn; t += SLICE_THREADS) s_cur[t] = row[t] + starts[tbase + t];
+        {   // cursor of tile t = start of the tile (exclusive scan of the totals) + this slice's offset inside it
+            const int i0 = threadIdx.x * EPT;
+            uint32_t v[EPT], tsum = 0;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) { v[e] = i0 + e < tn ? totals[tbase + i0 + e] : 0u; tsum += v[e]; }
+            uint32_t incl = tsum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += u;
+            }
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            uint32_t wbase = 0, chunk_total = 0;
+#pragma unroll
+            for (int w = 0; w < SLICE_THREADS / 64; w++) { if (w < wave) wbase += wtot[w]; chunk_total += wtot[w]; }
+            uint32_t st = chunk_base + wbase + incl - tsum;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = i0 + e;
+                if (i < tn) {
+                    s_cur[i] = st + row[i];
+                    if (blockIdx.x == 0) {
+                        ranges[2 * (tbase + i)] = v[e] ? st : 0u;
+                        ranges[2 * (tbase + i) + 1] = v[e] ? st + v[e] : 0u;
+                    }
+                }
+                st += v[e];
+            }
+            chunk_base += chunk_total;
+        }
         __syncthreads();
         for (int idx = first + threadIdx.x; idx < last; idx += SLICE_THREADS) {
             const SliceRect r = load_rect(splat, idx, gx, gy);
@@ -433,9 +431,8 @@ int gsr_tile_slices(int P, int* gpb_out)
     return ns;
 }
 
-void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* starts,
-                             uint32_t* order, uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
-                             hipStream_t s)
+void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
+                             uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int T = gx * gy;
@@ -444,9 +441,8 @@ void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* 
     const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
     hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table);
     hipLaunchKernelGGL(tile_colscan_kernel, dim3((T + 31) / 32), dim3(256), 0, s, T, ns, table, totals);
-    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(1024), 0, s, T, totals, starts, ranges, order);
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table, starts,
-                       reinterpret_cast<uint2*>(bins));
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table, totals, ranges,
+                       order, reinterpret_cast<uint2*>(bins));
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<const unsigned long long*>(bins),
                        point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
     hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<unsigned long long*>(bins), point_list,

@@ -29,7 +29,7 @@ struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
 };
 struct BinLayout {
-    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, flags, table, totals, starts, order, bytes;
+    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, bytes;
     uint32_t sort_blocks;
 };
 
@@ -83,7 +83,6 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
     L.vals_b = o; o = gsr_align(o + r * 4);
     L.hist_global = o; o = gsr_align(o + 8 * 256 * 4);
     L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
-    L.flags = o; o = gsr_align(o + r);  // per sorted instance: bit w = wave w of the tile blended it (forward -> backward)
     {   // tile binning (binning.hip): [slice][tile] counters, tile totals, tile starts
         int gpb;
         const size_t ns = (size_t)gsr_tile_slices(P, &gpb);
@@ -91,7 +90,6 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
         if (t == 0) t = 1;
         L.table = o; o = gsr_align(o + ns * t * 4);
         L.totals = o; o = gsr_align(o + t * 4);
-        L.starts = o; o = gsr_align(o + t * 4);
         L.order = o; o = gsr_align(o + t * 4);  // tiles by descending list length: launch order of the blend kernels
     }
     L.bytes = o;
@@ -133,9 +131,8 @@ void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_to
 int gsr_launch_radix_sort(uint64_t* ka, uint64_t* kb, uint32_t* va, uint32_t* vb, uint32_t n, int end_bit,
                           uint32_t* hist_global, uint32_t* hist_blocks, uint32_t nblocks, hipStream_t s);
 static inline int gsr_sort_result_in_b(int end_bit) { return (((end_bit + 7) / 8) & 1); }
-void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* starts,
-                             uint32_t* order, uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
-                             hipStream_t s);
+void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
+                             uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted, hipStream_t s);
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
