@@ -456,6 +456,19 @@ int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2,
     return check_hip("loss_backward");
 }
 
+int gsr_adam_step(int n_tensors, const gsr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream)
+{
+    static_assert(sizeof(gsr_adam_tensor) == sizeof(GsrAdamTensorHost), "ABI struct mismatch");
+    if (n_tensors < 0 || (n_tensors > 0 && !tensors)) return fail(-1, "invalid tensor list");
+    for (int k = 0; k < n_tensors; k++) {
+        const gsr_adam_tensor& t = tensors[k];
+        if (t.n < 0 || t.step < 1) return fail(-1, "adam: n must be >= 0 and step >= 1");
+        if (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) return fail(-1, "adam: NULL tensor pointer");
+    }
+    gsr_launch_adam(n_tensors, reinterpret_cast<const GsrAdamTensorHost*>(tensors), beta1, beta2, eps, (hipStream_t)stream);
+    return check_hip("adam_step");
+}
+
 size_t gsr_knn_scratch_bytes(int P) { return gsr_knn_scratch_layout_bytes(P); }
 
 int gsr_knn_mean_dist2(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, void* stream)

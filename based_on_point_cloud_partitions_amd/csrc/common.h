@@ -164,6 +164,12 @@ void gsr_launch_loss_forward(int C, int H, int W, const float* img1, const float
 void gsr_launch_loss_backward(int C, int H, int W, const float* img1, const float* img2, const float* maps, float lambda,
                               const float* grad_loss, float* dL_dimg1, hipStream_t s);
 
+struct GsrAdamTensorHost {  // = gsr_adam_tensor of the C ABI
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n; double lr; int64_t step;
+};
+int gsr_launch_adam(int n_tensors, const GsrAdamTensorHost* t, double beta1, double beta2, double eps, hipStream_t s);
+
 size_t gsr_knn_scratch_layout_bytes(int P);
 int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
 

@@ -121,23 +121,44 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
         image, _ = rasterize_gaussian_params(xyz, screenspace, f_dc, f_rest, op_raw, sc_raw, rot_raw, r.raster_settings)
         return image
 
+    from based_on_point_cloud_partitions_amd.optim import Adam as HipAdam
+
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    # arguments/__init__.py defaults x 1e-3: same arithmetic, but the scene (and with it R) stays put over the timed steps
+    lrs = tuple(1e-3 * v for v in (0.00016, 0.0025, 0.0025 / 20.0, 0.05, 0.005, 0.001))
+    saved = [p.detach().clone() for p in params]
+    groups = lambda: [{"params": [p], "lr": lr, "name": n} for p, lr, n in zip(params, lrs, names)]
+    torch_adam = torch.optim.Adam(groups(), lr=0.0, eps=1e-15)  # scene/gaussian_model.py:175
+    hip_adam = HipAdam(groups(), lr=0.0, eps=1e-15)
+    hip_l = lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)
     variants = (
-        ("raster_from_raw_params_reference_dataflow", render_reference, None),
-        ("raster_from_raw_params_fused", render_fused, None),
-        ("step_with_loss_reference_dataflow_torch_loss", render_reference, lambda im: torch_l1_ssim(im, gt, 0.2)),
-        ("step_with_loss_reference_dataflow_hip_loss", render_reference, lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)),
-        ("step_with_loss_fused_params_hip_loss", render_fused, lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)),
+        ("raster_from_raw_params_reference_dataflow", render_reference, None, None),
+        ("raster_from_raw_params_fused", render_fused, None, None),
+        ("step_with_loss_reference_dataflow_torch_loss", render_reference, lambda im: torch_l1_ssim(im, gt, 0.2), None),
+        ("step_with_loss_reference_dataflow_hip_loss", render_reference, hip_l, None),
+        ("step_with_loss_fused_params_hip_loss", render_fused, hip_l, None),
+        ("train_iteration_reference_dataflow_torch_loss_torch_adam", render_reference, lambda im: torch_l1_ssim(im, gt, 0.2), torch_adam),
+        ("train_iteration_hip_rasterizer_torch_activations_hip_loss_torch_adam", render_reference, hip_l, torch_adam),
+        ("train_iteration_fused_params_hip_loss_hip_adam", render_fused, hip_l, hip_adam),
     )
     res = {}
-    for name, render, loss in variants:
+    for name, render, loss, opt in variants:
+        with torch.no_grad():
+            for p, q in zip(params, saved):
+                p.copy_(q)
+
         def one(i):
             image = render(rasterizers[i % len(rasterizers)])
             if loss is None:
                 image.backward(dL)
             else:
                 loss(image).backward()
-            for p in params:
-                p.grad = None
+            if opt is not None:
+                opt.step()  # train.py:155-157
+                opt.zero_grad(set_to_none=True)
+            else:
+                for p in params:
+                    p.grad = None
         for i in range(4):
             one(i)
         torch.cuda.synchronize()
@@ -146,8 +167,23 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
             one(4 + i)
         torch.cuda.synchronize()
         res[name + "_ms"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
+    # the optimizer step alone, on the gradients of the last iteration's shape
+    for name, opt in (("adam_step_torch", torch_adam), ("adam_step_hip", hip_adam)):
+        for p in params:
+            p.grad = torch.full_like(p, 1e-4)
+        for _ in range(3):
+            opt.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            opt.step()
+        torch.cuda.synchronize()
+        res[name + "_ms"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
+        for p in params:
+            p.grad = None
     res["note"] = ("per-step ms from GaussianModel's raw parameters (exp/sigmoid/normalize/cat included): raster_* = forward + "
-                   "backward with a fixed dL/dcolor; step_with_loss_* add (1-0.2)*L1 + 0.2*(1-SSIM); context only, not the headline")
+                   "backward with a fixed dL/dcolor; step_with_loss_* add (1-0.2)*L1 + 0.2*(1-SSIM); train_iteration_* add the Adam step "
+                   "over the six parameter groups (29.5 M parameters); context only, not the headline")
     return res
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -125,6 +125,17 @@ int gsr_loss_forward(int C, int H, int W, const float* img1, const float* img2, 
                      size_t scratch_bytes, float* out3, void* stream);
 int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2, float lambda_dssim, const void* scratch,
                       size_t scratch_bytes, const float* grad_loss, float* dL_dimg1, void* stream);
+
+/* Optimizer step of the training loop: torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of
+ * scene/gaussian_model.py:164-175 / train.py:155-157 for ALL parameter tensors in one launch -- dense Adam, weight_decay = 0,
+ * amsgrad = False, in the arithmetic of torch's own kernels (csrc/adam.hip).  `tensors` is a HOST array; param / grad /
+ * exp_avg / exp_avg_sq are device pointers to n contiguous floats; lr is the tensor's param-group learning rate and `step`
+ * its step count AFTER this update (torch keeps one per parameter).  Parameters without a gradient are simply not listed. */
+typedef struct {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n; double lr; int64_t step;
+} gsr_adam_tensor;
+int gsr_adam_step(int n_tensors, const gsr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream);
 
 /* Test/inspection hook: copies the intermediates held in the opaque buffers into plain arrays (any output may
  * be NULL).  means2D[P][2], depths[P], conic_opacity[P][4], rgb[P][3], cov3D[P][6], clamped[P][3],

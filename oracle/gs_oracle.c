@@ -812,6 +812,30 @@ void orc_activate_backward(int P, int Mrest, const float* opacity_raw, const flo
     }
 }
 
+/* ------------------------------------------------------------------------
+ * Optimizer step: torch.optim.Adam(l, lr=0.0, eps=1e-15).step() as the reference runs it
+ * (/root/reference/scene/gaussian_model.py:164-175, train.py:155-157): torch/optim/adam.py `_single_tensor_adam` with
+ * weight_decay = 0, amsgrad = False, maximize = False.  The reference's arithmetic lives in its dependency torch (installed
+ * here: 2.10); restated with the fused multiply-adds torch's kernels use -- exp_avg.lerp_ = fma(w, g - m, m),
+ * addcmul_ = fma((1-beta2) g, g, v beta2), addcdiv_ = p + (value m) / denom -- and pinned against torch.optim.Adam on
+ * CPU by tests/test_adam.py.  Scalars follow the Python doubles of adam.py and are rounded to fp32 where torch's
+ * kernels receive them.
+ * ---------------------------------------------------------------------- */
+void orc_adam_step(long n, float* p, const float* g, float* m, float* v, double lr, double beta1, double beta2, double eps,
+                   long step)
+{
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float w = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), b2 = (float)beta2;
+    const float ss = (float)(-(lr / bc1)), bs = (float)sqrt(bc2), epsf = (float)eps;
+    for (long i = 0; i < n; i++) {
+        const float mi = fmaf(w, g[i] - m[i], m[i]);            /* CONTRACT-FMA (torch lerp) */
+        const float vi = fmaf(omb2 * g[i], g[i], v[i] * b2);    /* CONTRACT-FMA (torch addcmul) */
+        const float denom = sqrtf(vi) / bs + epsf;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] + (ss * mi) / denom;
+    }
+}
+
 /* checkFrustum, rasterizer_impl.cu:54-66 (+ auxiliary.h:139-164) */
 void orc_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
 {

@@ -199,6 +199,15 @@ def activate_backward(opacity_raw, scaling_raw, rotation_raw, g):
     return out
 
 
+def adam_step(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-15, step=1):
+    """One torch.optim.Adam update of a float32 array, in place on (p, m, v); `step` is the count after the update."""
+    L = lib()
+    for a in (p, g, m, v):
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.size == p.size
+    L.orc_adam_step(ctypes.c_long(p.size), _p(p, _f), _p(g, _f), _p(m, _f), _p(v, _f), ctypes.c_double(lr), ctypes.c_double(beta1),
+                    ctypes.c_double(beta2), ctypes.c_double(eps), ctypes.c_long(step))
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     L = lib()
     means3D = _f32(means3D)

@@ -1,0 +1,194 @@
+"""Optimizer step: `torch.optim.Adam(l, lr=0.0, eps=1e-15)` of scene/gaussian_model.py:164-175 as one
+HIP launch (based_on_point_cloud_partitions_amd.optim.Adam, C ABI gsr_adam_step).
+
+CPU part: the oracle's restatement (oracle/gs_oracle.c, orc_adam_step) is pinned against torch.optim.Adam itself (the
+reference's dependency, importable here): exp_avg / exp_avg_sq bit-exact, parameters within 1 ulp on a handful of
+elements.  GPU part: the HIP kernel is bit-exact against the oracle, agrees with torch's own device Adam to rounding,
+and survives the optimizer-state surgery the reference's densification performs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+
+# the six Gaussian parameter groups of training_setup (gaussian_model.py:164-171), learning rates of arguments/__init__.py
+GROUPS = [("xyz", (3,), 0.00016 * 5.0), ("f_dc", (1, 3), 0.0025), ("f_rest", (15, 3), 0.0025 / 20.0), ("opacity", (1,), 0.05),
+          ("scaling", (3,), 0.005), ("rotation", (4,), 0.001)]
+
+
+def make_params(P, seed=0, device="cpu"):
+    gen = torch.Generator().manual_seed(seed)
+    return [(name, torch.nn.Parameter((torch.randn((P,) + shape, generator=gen) * 0.5).to(device).requires_grad_(True)), lr)
+            for name, shape, lr in GROUPS]
+
+
+def param_groups(params):
+    return [{"params": [p], "lr": lr, "name": name} for name, p, lr in params]
+
+
+def grads_for(params, step, seed=0):
+    gen = torch.Generator().manual_seed(1000 * seed + step)
+    out = []
+    for name, p, _ in params:
+        g = torch.randn(p.shape, generator=gen) * (10.0 ** float(torch.randint(-6, 0, (1,), generator=gen)))
+        g[::7] = 0.0  # culled Gaussians have exactly zero gradients
+        out.append(g)
+    return out
+
+
+def ulp_close(a, b, floor, ulps=2, frac=2e-3):
+    """Equal up to `ulps` units in the last place of max(|a|, |b|, floor) on at most `frac` of the elements.  `floor` is the
+    size of the Adam update (~lr): the update term is rounded before it is added, so a parameter near zero inherits the
+    update's rounding, not its own."""
+    a, b = np.asarray(a, np.float32).ravel(), np.asarray(b, np.float32).ravel()
+    diff = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    scale = np.maximum(np.maximum(np.abs(a), np.abs(b)), np.float32(floor))
+    assert np.all(diff <= ulps * np.spacing(scale)), float(diff.max())
+    assert np.count_nonzero(diff) <= frac * a.size + 2
+
+
+def test_oracle_matches_torch_adam_on_cpu():
+    P = 20011
+    params = make_params(P)
+    opt = torch.optim.Adam(param_groups(params), lr=0.0, eps=1e-15, foreach=False)
+    mine = [(p.detach().numpy().copy(), np.zeros(p.numel(), np.float32), np.zeros(p.numel(), np.float32)) for _, p, _ in params]
+    for step in range(1, 8):
+        opt.param_groups[0]["lr"] = 0.0008 * 0.97 ** step  # update_learning_rate (gaussian_model.py:181-187)
+        gs = grads_for(params, step)
+        for (_, p, _), g in zip(params, gs):
+            p.grad = g.clone()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        for k, ((name, p, lr), g) in enumerate(zip(params, gs)):
+            pv, m, v = mine[k]
+            oracle.adam_step(pv.reshape(-1), g.numpy().reshape(-1), m, v, opt.param_groups[k]["lr"], 0.9, 0.999, 1e-15, step)
+            st = opt.state[p]
+            assert np.array_equal(m, st["exp_avg"].numpy().reshape(-1)), name
+            assert np.array_equal(v, st["exp_avg_sq"].numpy().reshape(-1)), name
+            ulp_close(pv, p.detach().numpy(), floor=10.0 * opt.param_groups[k]["lr"])
+            pv[...] = p.detach().numpy()  # follow torch so that single-ulp differences do not accumulate in the comparison
+
+
+def test_adam_refuses_cpu_parameters_and_bad_hyperparameters():
+    from based_on_point_cloud_partitions_amd import GsrError
+    from based_on_point_cloud_partitions_amd.optim import Adam
+
+    p = torch.nn.Parameter(torch.zeros(4))
+    opt = Adam([{"params": [p], "lr": 0.1, "name": "xyz"}], lr=0.0, eps=1e-15)
+    assert opt.param_groups[0]["name"] == "xyz" and opt.param_groups[0]["eps"] == 1e-15 and opt.param_groups[0]["betas"] == (0.9, 0.999)
+    opt.step()  # no gradient anywhere: nothing to do, no state
+    assert len(opt.state) == 0
+    p.grad = torch.ones(4)
+    with pytest.raises(GsrError):
+        opt.step()  # no CPU fallback
+    with pytest.raises(ValueError):
+        Adam([p], lr=-1.0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 1023, 20011])
+def test_hip_adam_bit_exact_vs_oracle_and_close_to_torch(P):
+    from based_on_point_cloud_partitions_amd.optim import Adam
+
+    params = make_params(P, seed=3, device="cuda")
+    twin = make_params(P, seed=3, device="cuda")
+    opt = Adam(param_groups(params), lr=0.0, eps=1e-15)
+    ref = torch.optim.Adam(param_groups(twin), lr=0.0, eps=1e-15)
+    mine = [(p.detach().cpu().numpy().copy(), np.zeros(p.numel(), np.float32), np.zeros(p.numel(), np.float32)) for _, p, _ in params]
+    for step in range(1, 7):
+        lr0 = 0.0008 * 0.97 ** step
+        opt.param_groups[0]["lr"] = ref.param_groups[0]["lr"] = lr0
+        gs = grads_for(params, step, seed=3)
+        for (_, p, _), (_, q, _), g in zip(params, twin, gs):
+            p.grad = g.cuda()
+            q.grad = g.cuda()
+        if step == 4:
+            params[3][1].grad = None  # a parameter without gradient is skipped and keeps its step count
+            twin[3][1].grad = None
+        opt.step()
+        ref.step()
+        opt.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        for k, ((name, p, lr), g) in enumerate(zip(params, gs)):
+            if step == 4 and k == 3:
+                continue
+            pv, m, v = mine[k]
+            nstep = step - 1 if (k == 3 and step > 4) else step
+            oracle.adam_step(pv.reshape(-1), g.numpy().reshape(-1), m, v, opt.param_groups[k]["lr"], 0.9, 0.999, 1e-15, nstep)
+            st = opt.state[p]
+            assert int(st["step"]) == nstep
+            assert np.array_equal(st["exp_avg"].cpu().numpy().reshape(-1), m), name
+            assert np.array_equal(st["exp_avg_sq"].cpu().numpy().reshape(-1), v), name
+            assert np.array_equal(p.detach().cpu().numpy().reshape(-1), pv.reshape(-1)), name
+            np.testing.assert_allclose(p.detach().cpu().numpy(), twin[k][1].detach().cpu().numpy(), rtol=2e-5, atol=1e-7)
+    assert set(opt.state[params[0][1]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.gpu
+def test_hip_adam_survives_densification_state_surgery_and_state_dict():
+    """cat_tensors_to_optimizer / _prune_optimizer (gaussian_model.py:297-370) swap the parameter object and resize the moments."""
+    from based_on_point_cloud_partitions_amd.optim import Adam
+
+    P = 3001
+    params = make_params(P, seed=5, device="cuda")
+    opt = Adam(param_groups(params), lr=0.0, eps=1e-15)
+    for step in (1, 2):
+        for (_, p, _), g in zip(params, grads_for(params, step, seed=5)):
+            p.grad = g.cuda()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    # densify: append 100 rows with zero moments; prune: keep a mask -- exactly the reference's code shape
+    keep = torch.rand(P + 100, generator=torch.Generator().manual_seed(9)) > 0.3
+    new_params = []
+    for group in opt.param_groups:
+        old = group["params"][0]
+        stored = opt.state.get(old, None)
+        ext = torch.zeros((100,) + old.shape[1:], device="cuda")
+        stored["exp_avg"] = torch.cat((stored["exp_avg"], torch.zeros_like(ext)), dim=0)[keep.cuda()]
+        stored["exp_avg_sq"] = torch.cat((stored["exp_avg_sq"], torch.zeros_like(ext)), dim=0)[keep.cuda()]
+        del opt.state[old]
+        group["params"][0] = torch.nn.Parameter(torch.cat((old.detach(), ext), dim=0)[keep.cuda()].requires_grad_(True))
+        opt.state[group["params"][0]] = stored
+        new_params.append(group["params"][0])
+    snap = [(p.detach().cpu().numpy().copy(), opt.state[p]["exp_avg"].cpu().numpy().copy(), opt.state[p]["exp_avg_sq"].cpu().numpy().copy())
+            for p in new_params]
+    import copy
+    sd = copy.deepcopy(opt.state_dict())  # capture() (gaussian_model.py:69-83); state_dict() hands out references
+    moments_before = [snap[k][1].copy() for k in range(len(snap))]
+    gen = torch.Generator().manual_seed(11)
+    gs = [torch.randn(p.shape, generator=gen) * 1e-3 for p in new_params]
+    for p, g in zip(new_params, gs):
+        p.grad = g.cuda()
+    opt.step()
+    for k, (p, g) in enumerate(zip(new_params, gs)):
+        pv, m, v = snap[k]
+        oracle.adam_step(pv.reshape(-1), g.numpy().reshape(-1), m.reshape(-1), v.reshape(-1), opt.param_groups[k]["lr"], 0.9, 0.999, 1e-15, 3)
+        assert np.array_equal(p.detach().cpu().numpy(), pv) and int(opt.state[p]["step"]) == 3
+    # restore(): a fresh optimizer over the same parameters loads the captured state
+    opt2 = Adam([{"params": [p], "lr": g["lr"], "name": g["name"]} for p, g in zip(new_params, opt.param_groups)], lr=0.0, eps=1e-15)
+    opt2.load_state_dict(sd)
+    for k, p in enumerate(new_params):
+        assert int(opt2.state[p]["step"]) == 2
+        assert np.array_equal(opt2.state[p]["exp_avg"].cpu().numpy(), moments_before[k])
+
+
+@pytest.mark.gpu
+def test_hip_adam_config2_sized_model():
+    """29.5 M parameters (500k Gaussians x 59): one launch, checked against the oracle."""
+    from based_on_point_cloud_partitions_amd.optim import Adam
+
+    P = 500_000
+    params = make_params(P, seed=1, device="cuda")
+    opt = Adam(param_groups(params), lr=0.0, eps=1e-15)
+    gs = grads_for(params, 1, seed=1)
+    before = [p.detach().cpu().numpy().copy() for _, p, _ in params]
+    for (_, p, _), g in zip(params, gs):
+        p.grad = g.cuda()
+    opt.step()
+    for k, ((name, p, lr), g) in enumerate(zip(params, gs)):
+        pv, m, v = before[k], np.zeros(p.numel(), np.float32), np.zeros(p.numel(), np.float32)
+        oracle.adam_step(pv.reshape(-1), g.numpy().reshape(-1), m, v, lr, 0.9, 0.999, 1e-15, 1)
+        assert np.array_equal(p.detach().cpu().numpy(), pv), name
+        assert np.array_equal(opt.state[p]["exp_avg_sq"].cpu().numpy().reshape(-1), v), name
