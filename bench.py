@@ -328,9 +328,12 @@ def main():
         for k in kernels:
             v = pmc.get(k["kernel"], {})
             if "sq_insts_valu" in v:
-                # wave64 VALU issue peak: one instruction per 2 cycles per SIMD (MI355X_MICROARCH.md), 1024 SIMDs, 2.4 GHz
+                # SIMD cycles this kernel spends per VALU wave-instruction (1024 SIMDs, 2.4 GHz).  Measured issue costs on
+                # gfx950 (tools/valu_cost.hip, profiles/r01_valu_cost.txt): plain VOP 2.4 cycles; v_cmp / v_cndmask / SGPR
+                # operands / DPP 4.3; v_exp / v_rcp / v_permlane*_swap 8.4 -- a kernel whose average sits between the first
+                # two is VALU-issue bound.
                 k["valu_insts"] = int(v["sq_insts_valu"])
-                k["valu_issue_frac"] = round(v["sq_insts_valu"] * 2.0 / (1024 * 2.4e9 * k["avg_ms"] * 1e-3), 3)
+                k["simd_cycles_per_valu_inst"] = round(1024 * 2.4e9 * k["avg_ms"] * 1e-3 / v["sq_insts_valu"], 2)
             if "hbm_bytes" in v:
                 k["hbm_traffic_MB"] = round(v["hbm_bytes"] / 1e6, 1)
         kernels.sort(key=lambda k: -k["avg_ms"])
