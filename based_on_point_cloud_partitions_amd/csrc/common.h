@@ -220,14 +220,14 @@ __device__ __forceinline__ void sh_tile_load(const float* __restrict__ g, float*
     const int count = rows * n3;
     if ((n3 & 3) == 0) {
         const float4* g4 = reinterpret_cast<const float4*>(g);
-        for (int f = threadIdx.x; f < (count >> 2); f += 256) {
+        for (int f = threadIdx.x; f < (count >> 2); f += blockDim.x) {
             const float4 v = g4[f];
             const int e = f << 2, r = e / n3, c = e - r * n3;
             float* d = s + r * stride + c;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     } else {
-        for (int e = threadIdx.x; e < count; e += 256) {
+        for (int e = threadIdx.x; e < count; e += blockDim.x) {
             const int r = e / n3, c = e - r * n3;
             s[r * stride + c] = g[e];
         }
@@ -238,13 +238,13 @@ __device__ __forceinline__ void sh_tile_store(float* __restrict__ g, const float
     const int count = rows * n3;
     if ((n3 & 3) == 0) {
         float4* g4 = reinterpret_cast<float4*>(g);
-        for (int f = threadIdx.x; f < (count >> 2); f += 256) {
+        for (int f = threadIdx.x; f < (count >> 2); f += blockDim.x) {
             const int e = f << 2, r = e / n3, c = e - r * n3;
             const float* d = s + r * stride + c;
             g4[f] = make_float4(d[0], d[1], d[2], d[3]);
         }
     } else {
-        for (int e = threadIdx.x; e < count; e += 256) {
+        for (int e = threadIdx.x; e < count; e += blockDim.x) {
             const int r = e / n3, c = e - r * n3;
             g[e] = s[r * stride + c];
         }
@@ -258,7 +258,7 @@ __device__ __forceinline__ void sh_cols_load(const float* __restrict__ g, float*
 {
     const int count = rows * ncols, n4 = count >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
-    for (int f = threadIdx.x; f < n4; f += 256) {
+    for (int f = threadIdx.x; f < n4; f += blockDim.x) {
         const float4 v = g4[f];
         const float e4[4] = {v.x, v.y, v.z, v.w};
         int r = (f << 2) / ncols, c = (f << 2) - r * ncols;
@@ -268,7 +268,7 @@ __device__ __forceinline__ void sh_cols_load(const float* __restrict__ g, float*
             if (++c == ncols) { c = 0; r++; }
         }
     }
-    for (int e = (n4 << 2) + threadIdx.x; e < count; e += 256) {
+    for (int e = (n4 << 2) + threadIdx.x; e < count; e += blockDim.x) {
         const int r = e / ncols, c = e - r * ncols;
         s[r * stride + col0 + c] = g[e];
     }
@@ -277,7 +277,7 @@ __device__ __forceinline__ void sh_cols_store(float* __restrict__ g, const float
 {
     const int count = rows * ncols, n4 = count >> 2;
     float4* g4 = reinterpret_cast<float4*>(g);
-    for (int f = threadIdx.x; f < n4; f += 256) {
+    for (int f = threadIdx.x; f < n4; f += blockDim.x) {
         float e4[4];
         int r = (f << 2) / ncols, c = (f << 2) - r * ncols;
 #pragma unroll
@@ -287,7 +287,7 @@ __device__ __forceinline__ void sh_cols_store(float* __restrict__ g, const float
         }
         g4[f] = make_float4(e4[0], e4[1], e4[2], e4[3]);
     }
-    for (int e = (n4 << 2) + threadIdx.x; e < count; e += 256) {
+    for (int e = (n4 << 2) + threadIdx.x; e < count; e += blockDim.x) {
         const int r = e / ncols, c = e - r * ncols;
         g[e] = s[r * stride + col0 + c];
     }

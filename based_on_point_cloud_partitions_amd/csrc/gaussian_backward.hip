@@ -41,14 +41,14 @@ struct GaussBackwardPtrs {
 // RAW (gsr_backward_params): scales / rotations are the pre-activation parameters; the chain rule through exp / sigmoid /
 // normalize is applied here and dL/dSH leaves LDS as the two tensors dL/dfeatures_dc, dL/dfeatures_rest -- the autograd
 // passes of scene/gaussian_model.py:102-122 (exp, sigmoid, normalize, cat backward) never touch HBM.
-template <bool RAW>
-__global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
+template <bool RAW, int BS>
+__global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
 {
-    extern __shared__ float s_tile[];  // [256][3M + 1]
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ float s_tile[];  // [BS][3M + 1]
+    const int idx = blockIdx.x * BS + threadIdx.x;
     const int M = a.M, n3 = 3 * M, stride = n3 + 1;
-    const int rows = min(256, a.P - (int)blockIdx.x * 256);
-    const size_t tile_base = (size_t)blockIdx.x * 256 * n3;
+    const int rows = min(BS, a.P - (int)blockIdx.x * BS);
+    const size_t tile_base = (size_t)blockIdx.x * BS * n3;
     const bool valid = idx < a.P;
     const bool visible = valid && a.radii[idx] > 0;
 
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
     // one dependent round trip per row and was 60 % of this kernel.
     float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {
-        const int first = blockIdx.x * 256, last = min(a.P, first + 256);
+        const int first = blockIdx.x * BS, last = min(a.P, first + BS);
         const uint32_t begin = first == 0 ? 0u : a.point_offsets[first - 1];
         const uint32_t end = (a.dbg & 1) ? begin : a.point_offsets[last - 1];
         uint32_t my_off = 0, my_n = 0;
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
         const float4* g4 = reinterpret_cast<const float4*>(a.grad_rows);
         for (uint32_t cb = begin; cb < end; cb += CH) {
             const uint32_t nrows = min(CH, end - cb);
-            for (uint32_t f = threadIdx.x; f < nrows * 3; f += 256) s_rows[f] = g4[(size_t)cb * 3 + f];
+            for (uint32_t f = threadIdx.x; f < nrows * 3; f += BS) s_rows[f] = g4[(size_t)cb * 3 + f];
             __syncthreads();
             const uint32_t lo = max(my_off, cb), hi = min(my_off + my_n, cb + nrows);
             for (uint32_t r = lo; r < hi; r++) {
@@ -86,8 +86,8 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
     }
 
     if (RAW) {
-        sh_cols_load(a.features_dc + (size_t)blockIdx.x * 256 * 3, s_tile, rows, 3, stride, 0);
-        if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * 256 * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
+        sh_cols_load(a.features_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
+        if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
     } else if (a.has_shs && !(a.dbg & 2)) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
     __syncthreads();
     float* __restrict__ my_row = s_tile + threadIdx.x * stride;  // SH in, dL/dSH out
@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(256) gaussian_backward_kernel(GaussBackwardPtr
     }
     __syncthreads();
     if (RAW) {
-        sh_cols_store(a.dL_dfeatures_dc + (size_t)blockIdx.x * 256 * 3, s_tile, rows, 3, stride, 0);
-        if (n3 > 3) sh_cols_store(a.dL_dfeatures_rest + (size_t)blockIdx.x * 256 * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
+        sh_cols_store(a.dL_dfeatures_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
+        if (n3 > 3) sh_cols_store(a.dL_dfeatures_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
     } else if (n3 > 0 && !(a.dbg & 4)) sh_tile_store(a.dL_dsh + tile_base, s_tile, rows, n3, stride);
 }
 
@@ -365,11 +365,15 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.P = a.P; p.D = a.D; p.M = a.M; p.has_shs = a.has_shs; p.has_scales = a.has_scales;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     p.dbg = gsr_variant("GB_DBG", 0);
-    size_t lds = (size_t)256 * (3 * a.M + 1) * 4;
-    if (lds < 1024 * GSR_GROW_F * 4) lds = 1024 * GSR_GROW_F * 4;  // room for 1024 gradient rows per chunk
+    const int bs = gsr_variant("GB_BLOCK", 128);
+    size_t lds = (size_t)bs * (3 * a.M + 1) * 4;
+    if (lds < (size_t)4 * bs * GSR_GROW_F * 4) lds = (size_t)4 * bs * GSR_GROW_F * 4;  // room for 4 gradient rows per Gaussian and chunk
     p.lds_floats = (int)(lds / 4);
-    if (a.raw)
-        hipLaunchKernelGGL(gaussian_backward_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
-    else
-        hipLaunchKernelGGL(gaussian_backward_kernel<false>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
+    if (bs == 256) {
+        if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256>), dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
+        else hipLaunchKernelGGL((gaussian_backward_kernel<false, 256>), dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
+    } else {
+        if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128>), dim3((a.P + 127) / 128), dim3(128), lds, s, p, h_x, h_y);
+        else hipLaunchKernelGGL((gaussian_backward_kernel<false, 128>), dim3((a.P + 127) / 128), dim3(128), lds, s, p, h_x, h_y);
+    }
 }

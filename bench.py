@@ -71,9 +71,10 @@ def cpu_baseline(cfg, g, cam, dL):
     t1 = time.perf_counter()
     oracle.backward(st, dL)
     t2 = time.perf_counter()
+    stats = {"pair_visits": int(st["stats"][0]), "blended_pairs": int(st["stats"][1])}  # camera 0, reference algorithm
     return {"value": 1.0 / (t2 - t0), "unit": "it/s", "cores": cores, "kind": "port",
             "sample": f"1 raster step (camera 0 of the {cfg['P']}-Gaussian {cfg['W']}x{cfg['H']} workload): "
-                      f"forward {t1 - t0:.2f} s + backward {t2 - t1:.2f} s, OpenMP over Gaussians/tiles"}
+                      f"forward {t1 - t0:.2f} s + backward {t2 - t1:.2f} s, OpenMP over Gaussians/tiles"}, stats
 
 
 def torch_l1_ssim(img, gt, lam):
@@ -365,7 +366,9 @@ def main():
             "workload_stats": {"P": P, "V_mean": round(V, 1), "R_mean": round(R, 1), "N": N, "key_bits": key_bits,
                                "tile_list_mean": round(float(np.mean([u["tile_mean"] for u in used])), 1),
                                "tile_list_max": int(max(u["tile_max"] for u in used)),
-                               "n_contrib_mean": round(float(np.mean([u["n_contrib_mean"] for u in used])), 1)},
+                               "n_contrib_mean": round(float(np.mean([u["n_contrib_mean"] for u in used])), 1),
+                               "per_camera": [{"V": u["V"], "R": u["R"], "tile_list_mean": round(u["tile_mean"], 1),
+                                               "tile_list_max": u["tile_max"]} for u in stats]},
             "knn_init_ms": knn_ms,
             "rendered_mpix_per_s_fwd": round(world * N / 1e6 / (fwd_ms * 1e-3), 1) if fwd_ms > 0 else None,
             "roofline": roofline,
@@ -377,7 +380,18 @@ def main():
         if full is not None:
             out["full_step"] = full
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, g, cams[0], dL_cpu.numpy())
+            out["cpu_baseline"], pairs = cpu_baseline(cfg, g, cams[0], dL_cpu.numpy())
+            # the blend kernels next to the fp32 vector peak.  Pair visits = (tile list entry, pixel) pairs the
+            # reference's loop evaluates until the pixel is done (oracle count, camera 0); ~11 flops per visit (power) and ~30
+            # more per blended pair in the forward, ~60 in the backward.
+            by = {k["kernel"]: k for k in kernels}
+            for name, per_visit, per_blend in (("render_forward", 11, 30), ("render_backward", 11, 60)):
+                if name in by:
+                    t = by[name]["avg_ms"] * 1e-3
+                    fl = pairs["pair_visits"] * per_visit + pairs["blended_pairs"] * per_blend
+                    by[name]["pair_loop"] = {"reference_pair_visits": pairs["pair_visits"], "blended_pairs": pairs["blended_pairs"],
+                                             "reference_pair_visits_per_s": round(pairs["pair_visits"] / t, 1),
+                                             "fp32_flops_est": int(fl), "fp32_vector_peak_frac": round(fl / t / 157.3e12, 4)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
