@@ -353,3 +353,33 @@ def test_knn_config2_points_and_fixture():
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     # the caller's post-processing (scene/gaussian_model.py:144-145) stays finite
     assert torch.isfinite(torch.log(torch.sqrt(torch.clamp_min(torch.from_numpy(got), 1e-7)))).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# randomised sweep: odd sizes, tiny and huge splats, extreme opacities, every SH degree
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration_sweep(seed):
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 4097]))
+    W, H = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+    deg = int(rng.integers(0, 4))
+    focal = float(rng.uniform(20.0, 200.0))
+    lo = float(10 ** rng.uniform(-3.5, -1.0))
+    hi = lo * float(10 ** rng.uniform(0.0, 2.5))  # up to splats far larger than the image
+    bg = tuple(float(v) for v in rng.uniform(0, 1, 3))
+    g, cam = scene(P, W, H, focal, seed=seed, scale_lo=lo, scale_hi=hi, cam_index=int(rng.integers(0, 4)))
+    # extreme opacities (exactly 0 and 1 included) and a few denormal-small scales
+    op = g.opacities.clone()
+    op[:: 5] = 1.0
+    op[1 :: 7] = 0.0
+    op[2 :: 11] = 1.0 / 255.0
+    g = syn.SyntheticGaussians(g.xyz, g.scales, g.rotations, op, g.shs)
+    mod = float(rng.choice([1.0, 0.5, 2.5]))
+    st = oracle_forward(g, cam, bg=bg, sh_degree=deg, scale_modifier=mod)
+    ctx = hip_forward_raw(g, cam, bg=bg, sh_degree=deg, scale_modifier=mod)
+    assert_forward_bit_exact(ctx, st)
+    dL = rng.standard_normal((3, H, W)).astype(np.float32)
+    assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
