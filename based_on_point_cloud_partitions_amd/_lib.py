@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -46,6 +46,10 @@ PROTOTYPES = {
                                     c_void_p, c_float, c_float, c_void_p, c_void_p, c_size, c_void_p, c_size, c_void_p, c_size,
                                     c_void_p, c_size] + [c_void_p] * 9),
     "gsr_adam_step": (c_int, [c_int, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
+    "gsr_densification_stats": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_compact_scratch_bytes": (c_size, [c_int]),
+    "gsr_compact_plan": (c_int, [c_int, c_void_p, c_void_p, c_size, ctypes.POINTER(c_i64), c_void_p]),
+    "gsr_compact_rows": (c_int, [c_int, c_void_p, c_void_p, c_size, c_int, c_void_p, c_void_p]),
     "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_loss_scratch_bytes": (c_size, [c_int, c_int, c_int]),
     "gsr_loss_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p]),
@@ -64,6 +68,11 @@ class AdamTensor(ctypes.Structure):
     """gsr_adam_tensor of include/gsrast_mi355x.h"""
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_i64),
                 ("lr", ctypes.c_double), ("step", c_i64)]
+
+
+class CompactTensor(ctypes.Structure):
+    """gsr_compact_tensor of include/gsrast_mi355x.h"""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("row_floats", c_i64)]
 
 
 class GsrError(RuntimeError):

@@ -469,6 +469,64 @@ int gsr_adam_step(int n_tensors, const gsr_adam_tensor* tensors, double beta1, d
     return check_hip("adam_step");
 }
 
+int gsr_densification_stats(int P, const int* radii, const float* viewspace_grad, float* max_radii2D, float* xyz_gradient_accum,
+                            float* denom, void* stream)
+{
+    if (P < 0) return fail(-1, "invalid P");
+    if (P == 0) return 0;
+    if (!radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom) return fail(-1, "NULL required pointer");
+    gsr_launch_densification_stats(P, radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom, (hipStream_t)stream);
+    return check_hip("densification_stats");
+}
+
+// scratch: block sums, block offsets (one u32 per 256 rows each), total
+static size_t compact_layout(int P, size_t* offsets_off, size_t* total_off)
+{
+    const size_t nb = ((size_t)(P > 0 ? P : 1) + 255) / 256;
+    size_t o = gsr_align(nb * 4);
+    *offsets_off = o; o = gsr_align(o + nb * 4);
+    *total_off = o; o = gsr_align(o + 16);
+    return o;
+}
+size_t gsr_compact_scratch_bytes(int P) { size_t a, b; return compact_layout(P, &a, &b); }
+
+int gsr_compact_plan(int P, const uint8_t* keep_mask, void* scratch, size_t scratch_bytes, int64_t* count_host, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!count_host) return fail(-1, "count_host is NULL");
+    *count_host = 0;
+    if (P < 0) return fail(-1, "invalid P");
+    if (P == 0) return 0;
+    size_t off, tot;
+    if (!keep_mask || !scratch || scratch_bytes < compact_layout(P, &off, &tot)) return fail(-3, "compact scratch too small");
+    char* c = (char*)scratch;
+    const int nb = (P + 255) / 256;
+    gsr_launch_compact_count(P, keep_mask, (uint32_t*)c, s);
+    gsr_launch_scan_blocks(nb, (const uint32_t*)c, (uint32_t*)(c + off), (uint32_t*)(c + tot), nullptr, 0, s);
+    uint32_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, c + tot, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(-100, "compact_plan: %s", hipGetErrorString(e));
+    *count_host = (int64_t)total;
+    return check_hip("compact_plan");
+}
+
+int gsr_compact_rows(int P, const uint8_t* keep_mask, const void* scratch, size_t scratch_bytes, int n_tensors,
+                     const gsr_compact_tensor* tensors, void* stream)
+{
+    static_assert(sizeof(gsr_compact_tensor) == sizeof(GsrCompactTensorHost), "ABI struct mismatch");
+    if (P < 0 || n_tensors < 0 || (n_tensors > 0 && !tensors)) return fail(-1, "invalid arguments");
+    if (P == 0 || n_tensors == 0) return 0;
+    size_t off, tot;
+    if (!keep_mask || !scratch || scratch_bytes < compact_layout(P, &off, &tot)) return fail(-3, "compact scratch too small");
+    for (int k = 0; k < n_tensors; k++)
+        if (tensors[k].row_floats < 0 || (tensors[k].row_floats > 0 && (!tensors[k].src || !tensors[k].dst)))
+            return fail(-1, "compact: bad tensor descriptor");
+    gsr_launch_compact_rows(P, keep_mask, (const uint32_t*)((const char*)scratch + off), n_tensors,
+                            reinterpret_cast<const GsrCompactTensorHost*>(tensors), (hipStream_t)stream);
+    return check_hip("compact_rows");
+}
+
 size_t gsr_knn_scratch_bytes(int P) { return gsr_knn_scratch_layout_bytes(P); }
 
 int gsr_knn_mean_dist2(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, void* stream)

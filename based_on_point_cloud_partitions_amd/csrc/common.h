@@ -170,6 +170,13 @@ struct GsrAdamTensorHost {  // = gsr_adam_tensor of the C ABI
 };
 int gsr_launch_adam(int n_tensors, const GsrAdamTensorHost* t, double beta1, double beta2, double eps, hipStream_t s);
 
+struct GsrCompactTensorHost { const float* src; float* dst; int64_t row_floats; };  // = gsr_compact_tensor of the C ABI
+void gsr_launch_densification_stats(int P, const int* radii, const float* vgrad, float* max_radii2D, float* accum, float* denom,
+                                    hipStream_t s);
+void gsr_launch_compact_count(int P, const uint8_t* keep, uint32_t* block_sums, hipStream_t s);
+void gsr_launch_compact_rows(int P, const uint8_t* keep, const uint32_t* block_offsets, int n_tensors, const GsrCompactTensorHost* t,
+                             hipStream_t s);
+
 size_t gsr_knn_scratch_layout_bytes(int P);
 int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
 

@@ -1,0 +1,105 @@
+// Per-iteration bookkeeping of the training loop around the rasterizer, fused:
+//  * densification statistics (train.py:140-142 + GaussianModel.add_densification_stats, scene/gaussian_model.py:433-435):
+//        max_radii2D[vis] = max(max_radii2D[vis], radii[vis]); xyz_gradient_accum[vis] += ||viewspace_grad[vis, :2]||;
+//        denom[vis] += 1          with vis = radii > 0
+//    three masked read-modify-writes in torch (each a nonzero + gather + scatter, with a device sync) -> one streaming pass;
+//  * order-preserving row compaction by a mask for ALL tensors of the model at once (the `t[mask]` of prune_points /
+//    _prune_optimizer, gaussian_model.py:297-331: 6 parameters, their 12 Adam moments and 3 statistics = 21 boolean
+//    indexings in the reference).
+// Integer / copy work, HBM-bound.
+#include "common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) densification_stats_kernel(int P, const int* __restrict__ radii, const float* __restrict__ vgrad,
+                                                                  float* __restrict__ max_radii2D, float* __restrict__ accum,
+                                                                  float* __restrict__ denom)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    const float gx = vgrad[3 * (size_t)i], gy = vgrad[3 * (size_t)i + 1];
+    accum[i] = accum[i] + sqrtf(gx * gx + gy * gy);
+    denom[i] = denom[i] + 1.0f;
+}
+
+// number of kept rows per 256-row block
+__global__ void __launch_bounds__(256) compact_count_kernel(int P, const uint8_t* __restrict__ keep, uint32_t* __restrict__ block_sums)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool k = i < P && keep[i] != 0;
+    const uint32_t c = __popcll(__builtin_amdgcn_ballot_w64(k));
+    __shared__ uint32_t w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+constexpr int COMPACT_MAX_TENSORS = 24;
+struct CompactTensor { const float* __restrict__ src; float* __restrict__ dst; int row_floats; };
+struct CompactArgs {
+    CompactTensor t[COMPACT_MAX_TENSORS];
+    int n_tensors;
+};
+
+// one workgroup per 256 source rows: destination row of every kept row, then the kept rows of each tensor are copied with
+// the element index running over the block's [256][row_floats] slab (coalesced reads, row-contiguous writes)
+__global__ void __launch_bounds__(256) compact_rows_kernel(int P, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ block_offsets,
+                                                           CompactArgs args)
+{
+    __shared__ uint32_t s_pos[256];  // destination row, or 0xFFFFFFFF
+    __shared__ uint32_t w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * 256;
+    const int i = first + threadIdx.x;
+    const bool k = i < P && keep[i] != 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(k);
+    if (lane == 0) w[wave] = __popcll(m);
+    __syncthreads();
+    uint32_t base = block_offsets[blockIdx.x];
+    for (int q = 0; q < wave; q++) base += w[q];
+    s_pos[threadIdx.x] = k ? base + __popcll(m & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+    __syncthreads();
+    const int rows = min(256, P - first);
+    for (int ti = 0; ti < args.n_tensors; ti++) {
+        const CompactTensor t = args.t[ti];
+        const int rf = t.row_floats;
+        const float* src = t.src + (size_t)first * rf;
+        const int count = rows * rf;
+        for (int e = threadIdx.x; e < count; e += 256) {
+            const int r = e / rf, c = e - r * rf;
+            const uint32_t d = s_pos[r];
+            if (d != 0xFFFFFFFFu) t.dst[(size_t)d * rf + c] = src[e];
+        }
+    }
+}
+
+}  // namespace
+
+void gsr_launch_densification_stats(int P, const int* radii, const float* vgrad, float* max_radii2D, float* accum, float* denom, hipStream_t s)
+{
+    hipLaunchKernelGGL(densification_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, vgrad, max_radii2D, accum, denom);
+}
+
+void gsr_launch_compact_count(int P, const uint8_t* keep, uint32_t* block_sums, hipStream_t s)
+{
+    hipLaunchKernelGGL(compact_count_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, keep, block_sums);
+}
+
+void gsr_launch_compact_rows(int P, const uint8_t* keep, const uint32_t* block_offsets, int n_tensors, const GsrCompactTensorHost* t,
+                             hipStream_t s)
+{
+    for (int first = 0; first < n_tensors; first += COMPACT_MAX_TENSORS) {
+        CompactArgs a;
+        a.n_tensors = 0;
+        for (int k = first; k < n_tensors && a.n_tensors < COMPACT_MAX_TENSORS; k++) {
+            if (t[k].row_floats <= 0) continue;
+            a.t[a.n_tensors].src = t[k].src; a.t[a.n_tensors].dst = t[k].dst; a.t[a.n_tensors].row_floats = (int)t[k].row_floats;
+            a.n_tensors++;
+        }
+        if (a.n_tensors > 0)
+            hipLaunchKernelGGL(compact_rows_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, keep, block_offsets, a);
+    }
+}

@@ -113,16 +113,33 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
 
     def render_reference(r):  # gaussian_renderer/__init__.py:52-93 with the getters of gaussian_model.py:102-122
         screenspace = torch.zeros_like(xyz, requires_grad=True)
-        image, _ = r(means3D=xyz, means2D=screenspace, opacities=torch.sigmoid(op_raw), shs=torch.cat((f_dc, f_rest), dim=1),
-                     scales=torch.exp(sc_raw), rotations=torch.nn.functional.normalize(rot_raw))
-        return image
+        image, radii = r(means3D=xyz, means2D=screenspace, opacities=torch.sigmoid(op_raw), shs=torch.cat((f_dc, f_rest), dim=1),
+                         scales=torch.exp(sc_raw), rotations=torch.nn.functional.normalize(rot_raw))
+        return image, screenspace, radii
 
     def render_fused(r):
         screenspace = torch.zeros_like(xyz, requires_grad=True)
-        image, _ = rasterize_gaussian_params(xyz, screenspace, f_dc, f_rest, op_raw, sc_raw, rot_raw, r.raster_settings)
-        return image
+        image, radii = rasterize_gaussian_params(xyz, screenspace, f_dc, f_rest, op_raw, sc_raw, rot_raw, r.raster_settings)
+        return image, screenspace, radii
 
     from based_on_point_cloud_partitions_amd.optim import Adam as HipAdam
+    from based_on_point_cloud_partitions_amd.densify import add_densification_stats
+
+    class Stats:  # the three statistics tensors of GaussianModel (gaussian_model.py:160-161, :57)
+        pass
+    stats = Stats()
+    stats.max_radii2D = torch.zeros(xyz.shape[0], device=dev)
+    stats.xyz_gradient_accum = torch.zeros(xyz.shape[0], 1, device=dev)
+    stats.denom = torch.zeros(xyz.shape[0], 1, device=dev)
+
+    def stats_reference(vsp, radii):  # train.py:140-142 + add_densification_stats (gaussian_model.py:433-435), verbatim
+        vis = radii > 0
+        stats.max_radii2D[vis] = torch.max(stats.max_radii2D[vis], radii[vis])
+        stats.xyz_gradient_accum[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)
+        stats.denom[vis] += 1
+
+    def stats_fused(vsp, radii):
+        add_densification_stats(stats, vsp, radii)
 
     names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
     # arguments/__init__.py defaults x 1e-3: same arithmetic, but the scene (and with it R) stays put over the timed steps
@@ -133,27 +150,32 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
     hip_adam = HipAdam(groups(), lr=0.0, eps=1e-15)
     hip_l = lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)
     variants = (
-        ("raster_from_raw_params_reference_dataflow", render_reference, None, None),
-        ("raster_from_raw_params_fused", render_fused, None, None),
-        ("step_with_loss_reference_dataflow_torch_loss", render_reference, lambda im: torch_l1_ssim(im, gt, 0.2), None),
-        ("step_with_loss_reference_dataflow_hip_loss", render_reference, hip_l, None),
-        ("step_with_loss_fused_params_hip_loss", render_fused, hip_l, None),
-        ("train_iteration_reference_dataflow_torch_loss_torch_adam", render_reference, lambda im: torch_l1_ssim(im, gt, 0.2), torch_adam),
-        ("train_iteration_hip_rasterizer_torch_activations_hip_loss_torch_adam", render_reference, hip_l, torch_adam),
-        ("train_iteration_fused_params_hip_loss_hip_adam", render_fused, hip_l, hip_adam),
+        ("raster_from_raw_params_reference_dataflow", render_reference, None, None, None),
+        ("raster_from_raw_params_fused", render_fused, None, None, None),
+        ("step_with_loss_reference_dataflow_torch_loss", render_reference, lambda im: torch_l1_ssim(im, gt, 0.2), None, None),
+        ("step_with_loss_reference_dataflow_hip_loss", render_reference, hip_l, None, None),
+        ("step_with_loss_fused_params_hip_loss", render_fused, hip_l, None, None),
+        ("train_iteration_reference_dataflow_torch_loss_torch_adam_torch_stats", render_reference,
+         lambda im: torch_l1_ssim(im, gt, 0.2), torch_adam, stats_reference),
+        ("train_iteration_hip_rasterizer_torch_activations_hip_loss_torch_adam_torch_stats", render_reference, hip_l, torch_adam,
+         stats_reference),
+        ("train_iteration_fused_params_hip_loss_hip_adam_hip_stats", render_fused, hip_l, hip_adam, stats_fused),
     )
     res = {}
-    for name, render, loss, opt in variants:
+    for name, render, loss, opt, upd in variants:
         with torch.no_grad():
             for p, q in zip(params, saved):
                 p.copy_(q)
 
         def one(i):
-            image = render(rasterizers[i % len(rasterizers)])
+            image, vsp, radii = render(rasterizers[i % len(rasterizers)])
             if loss is None:
                 image.backward(dL)
             else:
                 loss(image).backward()
+            if upd is not None:
+                with torch.no_grad():
+                    upd(vsp, radii)
             if opt is not None:
                 opt.step()  # train.py:155-157
                 opt.zero_grad(set_to_none=True)
@@ -183,8 +205,8 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
         for p in params:
             p.grad = None
     res["note"] = ("per-step ms from GaussianModel's raw parameters (exp/sigmoid/normalize/cat included): raster_* = forward + "
-                   "backward with a fixed dL/dcolor; step_with_loss_* add (1-0.2)*L1 + 0.2*(1-SSIM); train_iteration_* add the Adam step "
-                   "over the six parameter groups (29.5 M parameters); context only, not the headline")
+                   "backward with a fixed dL/dcolor; step_with_loss_* add (1-0.2)*L1 + 0.2*(1-SSIM); train_iteration_* add the densification statistics "
+                   "(train.py:140-142) and the Adam step over the six parameter groups (29.5 M parameters); context only, not the headline")
     return res
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -136,6 +136,23 @@ typedef struct {
     int64_t n; double lr; int64_t step;
 } gsr_adam_tensor;
 int gsr_adam_step(int n_tensors, const gsr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream);
+
+/* Per-iteration densification statistics (train.py:140-142 + GaussianModel.add_densification_stats,
+ * scene/gaussian_model.py:433-435) in one pass, with vis = radii > 0:
+ *   max_radii2D[vis] = max(max_radii2D[vis], radii[vis]); xyz_gradient_accum[vis] += ||viewspace_grad[vis, :2]||; denom[vis] += 1.
+ * viewspace_grad is the [P][3] gradient of the screen-space points (gsr_backward's dL_dmeans2D). */
+int gsr_densification_stats(int P, const int* radii, const float* viewspace_grad, float* max_radii2D, float* xyz_gradient_accum,
+                            float* denom, void* stream);
+
+/* Order-preserving compaction of the rows of many [P][row_floats] float tensors by one byte mask (keep != 0): the boolean
+ * indexing `t[mask]` that prune_points / _prune_optimizer (scene/gaussian_model.py:297-331) apply to 21 tensors one by one.
+ * gsr_compact_plan scans the mask and returns the number of kept rows (it waits for it: the caller sizes the outputs);
+ * gsr_compact_rows then copies the kept rows of every listed tensor (host array of descriptors, device pointers). */
+typedef struct { const float* src; float* dst; int64_t row_floats; } gsr_compact_tensor;
+size_t gsr_compact_scratch_bytes(int P);
+int gsr_compact_plan(int P, const uint8_t* keep_mask, void* scratch, size_t scratch_bytes, int64_t* count_host, void* stream);
+int gsr_compact_rows(int P, const uint8_t* keep_mask, const void* scratch, size_t scratch_bytes, int n_tensors,
+                     const gsr_compact_tensor* tensors, void* stream);
 
 /* Test/inspection hook: copies the intermediates held in the opaque buffers into plain arrays (any output may
  * be NULL).  means2D[P][2], depths[P], conic_opacity[P][4], rgb[P][3], cov3D[P][6], clamped[P][3],

@@ -208,6 +208,18 @@ def adam_step(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-15, step=1):
                     ctypes.c_double(beta2), ctypes.c_double(eps), ctypes.c_long(step))
 
 
+def densification_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom):
+    """train.py:140-142 + GaussianModel.add_densification_stats (scene/gaussian_model.py:433-435), numpy restatement, in place."""
+    vis = np.asarray(radii) > 0
+    g = np.asarray(viewspace_grad, np.float32)
+    max_radii2D[vis] = np.maximum(max_radii2D[vis], np.asarray(radii)[vis].astype(np.float32))
+    n = np.sqrt((g[:, 0] * g[:, 0] + g[:, 1] * g[:, 1]).astype(np.float32)).astype(np.float32)
+    acc = xyz_gradient_accum.reshape(-1)
+    acc[vis] = (acc[vis] + n[vis]).astype(np.float32)
+    d = denom.reshape(-1)
+    d[vis] = d[vis] + np.float32(1.0)
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     L = lib()
     means3D = _f32(means3D)
