@@ -34,7 +34,7 @@ struct GaussBackwardPtrs {
     float* __restrict__ dL_drots;
     const float* __restrict__ features_dc; const float* __restrict__ features_rest;
     float* __restrict__ dL_dfeatures_dc; float* __restrict__ dL_dfeatures_rest;
-    int P, D, M, has_shs, has_scales, dbg, lds_floats;
+    int P, D, M, has_shs, has_scales, lds_floats;
     float scale_modifier, tan_fovx, tan_fovy;
 };
 
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     {
         const int first = blockIdx.x * BS, last = min(a.P, first + BS);
         const uint32_t begin = first == 0 ? 0u : a.point_offsets[first - 1];
-        const uint32_t end = (a.dbg & 1) ? begin : a.point_offsets[last - 1];
+        const uint32_t end = a.point_offsets[last - 1];
         uint32_t my_off = 0, my_n = 0;
         if (visible) {
             my_off = __float_as_uint(a.splat[(size_t)idx * GSR_SPLAT_F + SP_OFFS]);
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     if (RAW) {
         sh_cols_load(a.features_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
         if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
-    } else if (a.has_shs && !(a.dbg & 2)) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
+    } else if (a.has_shs) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
     __syncthreads();
     float* __restrict__ my_row = s_tile + threadIdx.x * stride;  // SH in, dL/dSH out
 
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     if (RAW) {
         sh_cols_store(a.dL_dfeatures_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
         if (n3 > 3) sh_cols_store(a.dL_dfeatures_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
-    } else if (n3 > 0 && !(a.dbg & 4)) sh_tile_store(a.dL_dsh + tile_base, s_tile, rows, n3, stride);
+    } else if (n3 > 0) sh_tile_store(a.dL_dsh + tile_base, s_tile, rows, n3, stride);
 }
 
 }  // namespace
@@ -364,7 +364,6 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.dL_dfeatures_dc = a.dL_dfeatures_dc; p.dL_dfeatures_rest = a.dL_dfeatures_rest;
     p.P = a.P; p.D = a.D; p.M = a.M; p.has_shs = a.has_shs; p.has_scales = a.has_scales;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
-    p.dbg = gsr_variant("GB_DBG", 0);
     const int bs = gsr_variant("GB_BLOCK", 128);
     size_t lds = (size_t)bs * (3 * a.M + 1) * 4;
     if (lds < (size_t)4 * bs * GSR_GROW_F * 4) lds = (size_t)4 * bs * GSR_GROW_F * 4;  // room for 4 gradient rows per Gaussian and chunk

@@ -97,3 +97,10 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_graft_entry_build_runs_and_checks_the_abi_version():
+    """build() is the driver's "does it build" check; it must not pin a stale ABI number."""
+    import __graft_entry__ as g
+
+    g.build()
