@@ -21,7 +21,6 @@
 namespace {
 
 constexpr int TCHUNK = 16384;       // tiles histogrammed per pass (64 KB of LDS counters)
-constexpr int SORT_CAP = 4096;      // list entries sorted in LDS (32 KB); longer lists are sorted in place in HBM
 
 struct SliceRect {
     uint32_t mnx, mny, mxx, mxy, dbits;
@@ -245,19 +244,21 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr a, uint32_t n, uint32_t N
 // (depth, id) key.  ~10 LDS operations per entry instead of the ~100 of a bitonic network (which is what limited the
 // first version: it was LDS-bandwidth bound).  A bucket that grows past BUCKET_LIMIT (many equal depths) sends the
 // tile to the bitonic path, so the worst case stays n log^2 n.
-constexpr int BUCKET_CAP = 2048;
+constexpr int BUCKET_CAP = 2048;      // lists sorted by a 256-thread workgroup (tile_sort_small_kernel)
+constexpr int BUCKET_CAP_MID = 8192;  // lists sorted by a 1024-thread workgroup (tile_sort_mid_kernel)
 constexpr int BUCKET_LIMIT = 16;
+template <int CAP, int THREADS>
 struct BucketSortLds {
-    unsigned long long keys[BUCKET_CAP];
-    uint32_t cnt[BUCKET_CAP + 1];
-    uint32_t red[8];
-    uint32_t wsum[4];
+    unsigned long long keys[CAP];
+    uint32_t cnt[CAP + 1];
+    uint32_t red[2 * THREADS / 64];
+    uint32_t wsum[THREADS / 64];
     int overflow;
 };
 
-// BUCKET_EPT = entries (and buckets) per thread: 2, 4 or 8 for lists of up to 512, 1024, 2048 entries
-template <int BUCKET_EPT>
-__device__ __forceinline__ void bucket_sort_tile(BucketSortLds& L, uint32_t tile, uint32_t r0, uint32_t n, uint32_t N,
+// BUCKET_EPT = entries (and buckets) per thread: 2, 4 or 8 for lists of up to 2, 4 or 8 x THREADS entries
+template <int BUCKET_EPT, int THREADS, int CAP>
+__device__ __forceinline__ void bucket_sort_tile(BucketSortLds<CAP, THREADS>& L, uint32_t tile, uint32_t r0, uint32_t n, uint32_t N,
                                                  const unsigned long long* __restrict__ bins, uint32_t* __restrict__ point_list,
                                                  unsigned long long* __restrict__ keys_sorted)
 {
@@ -272,7 +273,7 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds& L, uint32_t tile
     uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
 #pragma unroll
     for (int e = 0; e < BUCKET_EPT; e++) {
-        const uint32_t i = tid + 256 * e;
+        const uint32_t i = tid + THREADS * e;
         key[e] = i < n ? seg[i] : ~0ull;
         if (i < n) { const uint32_t d = (uint32_t)(key[e] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
     }
@@ -281,18 +282,19 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds& L, uint32_t tile
         dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, off, 64));
         dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
     }
-    if (lane == 0) { s_red[wave] = dmin; s_red[4 + wave] = dmax; }
-    for (uint32_t b = tid; b <= N; b += 256) s_cnt[b] = 0;
+    constexpr int WAVES = THREADS / 64;
+    if (lane == 0) { s_red[wave] = dmin; s_red[WAVES + wave] = dmax; }
+    for (uint32_t b = tid; b <= N; b += THREADS) s_cnt[b] = 0;
     if (tid == 0) s_overflow = 0;
     __syncthreads();
-    dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-    dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[WAVES + w]); }
     // monotone map depth bits -> bucket (float rounding is monotone, so equal or larger depth never gets a smaller bucket)
     const float inv = (float)N / ((float)(dmax - dmin) + 1.0f);
     uint32_t bucket[BUCKET_EPT];
 #pragma unroll
     for (int e = 0; e < BUCKET_EPT; e++) {
-        const uint32_t i = tid + 256 * e;
+        const uint32_t i = tid + THREADS * e;
         bucket[e] = 0;
         if (i < n) {
             const uint32_t d = (uint32_t)(key[e] >> 32);
@@ -336,7 +338,7 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds& L, uint32_t tile
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < BUCKET_EPT; e++) {
-            const uint32_t i = tid + 256 * e;
+            const uint32_t i = tid + THREADS * e;
             if (i < n) s_keys[i] = key[e];
         }
         __syncthreads();
@@ -344,7 +346,7 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds& L, uint32_t tile
     } else {
 #pragma unroll
         for (int e = 0; e < BUCKET_EPT; e++) {
-            const uint32_t i = tid + 256 * e;
+            const uint32_t i = tid + THREADS * e;
             if (i < n) s_keys[atomicAdd(&s_cnt[bucket[e]], 1u)] = key[e];
         }
         __syncthreads();
@@ -358,7 +360,7 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds& L, uint32_t tile
         }
         __syncthreads();
     }
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += THREADS) {
         const unsigned long long k = s_keys[i];
         point_list[r0 + i] = (uint32_t)k;
         if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
@@ -370,49 +372,69 @@ __global__ void __launch_bounds__(256) tile_sort_small_kernel(const uint32_t* __
                                                               uint32_t* __restrict__ point_list,
                                                               unsigned long long* __restrict__ keys_sorted)
 {
-    __shared__ BucketSortLds L;
+    __shared__ BucketSortLds<BUCKET_CAP, 256> L;
     const uint32_t tile = blockIdx.x;
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
     const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const uint32_t n = r1 - r0;
-    if (n == 0 || n > BUCKET_CAP) return;  // empty, or handled by tile_sort_large_kernel
+    if (n == 0 || n > BUCKET_CAP) return;  // empty, or handled by tile_sort_mid_kernel / tile_sort_large_kernel
     uint32_t N = 1;
     while (N < n) N <<= 1;
-    if (N <= 512) bucket_sort_tile<2>(L, tile, r0, n, N, bins, point_list, keys_sorted);
-    else if (N <= 1024) bucket_sort_tile<4>(L, tile, r0, n, N, bins, point_list, keys_sorted);
-    else bucket_sort_tile<8>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+    if (N <= 512) bucket_sort_tile<2, 256, BUCKET_CAP>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+    else if (N <= 1024) bucket_sort_tile<4, 256, BUCKET_CAP>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+    else bucket_sort_tile<8, 256, BUCKET_CAP>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+}
+
+// (5a') lists of 2049..8192 entries (dense scenes: the 2M-Gaussian configuration has a mean list length of ~1900): the same
+// bucket sort with 1024 threads and 96 KB of LDS; the bitonic network took 0.8 ms per frame there.
+__global__ void __launch_bounds__(1024) tile_sort_mid_kernel(int T, const uint32_t* __restrict__ order,
+                                                             const uint32_t* __restrict__ ranges,
+                                                             const unsigned long long* __restrict__ bins,
+                                                             uint32_t* __restrict__ point_list,
+                                                             unsigned long long* __restrict__ keys_sorted)
+{
+    __shared__ BucketSortLds<BUCKET_CAP_MID, 1024> L;
+    // `order` lists the tiles by descending length class and every list of 2040+ entries is in its first class, so the
+    // workgroups stride over the front of `order` and stop at the first shorter list (no launch of T mostly idle workgroups)
+    for (int i = blockIdx.x; i < T; i += gridDim.x) {
+        const uint32_t tile = order[i];
+        const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+        const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
+        const uint32_t n = r1 - r0;
+        if (n < 2040) break;
+        if (n <= BUCKET_CAP || n > BUCKET_CAP_MID) continue;
+        uint32_t N = 1;
+        while (N < n) N <<= 1;
+        if (N <= 4096) bucket_sort_tile<4, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+        else bucket_sort_tile<8, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+        __syncthreads();  // the LDS image is reused by the next list
+    }
 }
 
 // (5b) one workgroup per tile, lists longer than BUCKET_CAP: bitonic network in LDS (<= SORT_CAP) or in place in HBM.
-__global__ void __launch_bounds__(256) tile_sort_large_kernel(const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ bins,
+__global__ void __launch_bounds__(256) tile_sort_large_kernel(int T, const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ bins,
                                                               uint32_t* __restrict__ point_list, unsigned long long* __restrict__ keys_sorted)
 {
-    __shared__ unsigned long long s_keys[SORT_CAP];
-    const uint32_t tile = blockIdx.x;
-    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
-    const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
-    const uint32_t n = r1 - r0;
-    if (n <= BUCKET_CAP) return;
-    uint32_t N = 1;
-    while (N < n) N <<= 1;
-    unsigned long long* seg = bins + r0;
-    if (n <= SORT_CAP) {
-        for (uint32_t i = threadIdx.x; i < n; i += 256) s_keys[i] = seg[i];
-        __syncthreads();
-        bitonic_sort_block<true>(s_keys, n, N);
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const unsigned long long k = s_keys[i];
-            point_list[r0 + i] = (uint32_t)k;
-            if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
-        }
-    } else {
-        // rare: list longer than the LDS budget -> same network in place in HBM (workgroup-scope visibility via __syncthreads)
+    for (int i = blockIdx.x; i < T; i += gridDim.x) {
+        const uint32_t tile = order[i];
+        const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+        const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
+        const uint32_t n = r1 - r0;
+        if (n < 2040) break;  // see tile_sort_mid_kernel
+        if (n <= BUCKET_CAP_MID) continue;
+        uint32_t N = 1;
+        while (N < n) N <<= 1;
+        unsigned long long* seg = bins + r0;
+        // rare: list longer than the LDS budget -> normalized bitonic network in place in HBM (workgroup-scope visibility via
+        // __syncthreads)
         bitonic_sort_block<false>(seg, n, N);
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const unsigned long long k = seg[i];
-            point_list[r0 + i] = (uint32_t)k;
-            if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
+        for (uint32_t k = threadIdx.x; k < n; k += 256) {
+            const unsigned long long key = seg[k];
+            point_list[r0 + k] = (uint32_t)key;
+            if (keys_sorted) keys_sorted[r0 + k] = ((unsigned long long)tile << 32) | (key >> 32);
         }
+        __syncthreads();
     }
 }
 
@@ -445,6 +467,8 @@ void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* 
                        order, reinterpret_cast<uint2*>(bins));
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<const unsigned long long*>(bins),
                        point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
-    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<unsigned long long*>(bins), point_list,
-                       reinterpret_cast<unsigned long long*>(keys_sorted));
+    hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, order, ranges,
+                       reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
+    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 64 ? T : 64), dim3(256), 0, s, T, order, ranges,
+                       reinterpret_cast<unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
 }

@@ -100,11 +100,11 @@ def test_long_tile_lists_multiple_batches():
 
 
 def test_very_long_tile_lists_use_the_in_place_sort_path():
-    # > 4096 entries per tile: the per-tile sort leaves LDS and runs in place in HBM (binning.hip); lists of 1k..4k
-    # entries exercise the larger LDS networks
-    st, _ = _fwd_bwd(P=120_000, W=64, H=64, focal=40.0, seed=13, scale_lo=0.004, scale_hi=0.02)
+    # > 8192 entries per tile: the per-tile sort leaves LDS and runs in place in HBM (tile_sort_large_kernel); lists of
+    # 2049..8192 entries take the 1024-thread bucket sort (tile_sort_mid_kernel), 1k..2k the larger 256-thread ones
+    st, _ = _fwd_bwd(P=100_000, W=128, H=128, focal=80.0, seed=14, scale_lo=0.004, scale_hi=0.03)
     ln = st["ranges"][:, 1] - st["ranges"][:, 0]
-    assert ln.max() > 4096
+    assert (ln > 8192).any() and ((ln > 2048) & (ln <= 4096)).any() and ((ln > 4096) & (ln <= 8192)).any()
     st, _ = _fwd_bwd(P=60_000, W=96, H=96, focal=60.0, seed=14, scale_lo=0.004, scale_hi=0.03)
     ln = st["ranges"][:, 1] - st["ranges"][:, 0]
     assert ((ln > 1024) & (ln <= 4096)).any()
@@ -128,6 +128,24 @@ def test_many_equal_depths_tie_break_by_index():
     assert (keys[1:] == keys[:-1]).mean() > 0.5  # most neighbours in the sorted list are exact ties
     dL = np.random.default_rng(1).standard_normal((3, 128, 128)).astype(np.float32)
     assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+
+
+def test_equal_depths_in_mid_length_lists_overflow_to_the_network():
+    # thousands of exact depth ties in lists of 2049..8192 entries: the 1024-thread bucket sort overflows a bucket and
+    # falls back to the bitonic network, still in LDS
+    import torch
+
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    g, cam = scene(200, 32, 32, 30.0, seed=21, scale_lo=0.05, scale_hi=0.2)
+    rep = 60
+    idx = torch.randperm(200 * rep, generator=torch.Generator().manual_seed(1)) % 200
+    g2 = syn.SyntheticGaussians(g.xyz[idx], g.scales[idx], g.rotations[idx], g.opacities[idx] * 0.05, g.shs[idx])
+    st = oracle_forward(g2, cam)
+    ln = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert ((ln > 2048) & (ln <= 8192)).any()
+    ctx = hip_forward_raw(g2, cam)
+    assert_forward_bit_exact(ctx, st)
 
 
 def test_more_than_16384_tiles_multi_chunk_binning():

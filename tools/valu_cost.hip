@@ -112,15 +112,68 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
         } else if (KIND == 27) {
             asm volatile(REP16("v_mul_f32 %0, %0, %1\n v_mul_f32 %1, %1, %2\n s_nop 0\n v_mul_f32 %2, %2, %3\n v_mul_f32 %3, %3, %0\n s_nop 0\n")
                          : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 28) {
+            asm volatile(REP16("v_bfi_b32 %0, %4, %1, %2\n v_bfi_b32 %1, %4, %2, %3\n v_bfi_b32 %2, %4, %3, %0\n v_bfi_b32 %3, %4, %0, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));
+        } else if (KIND == 29) {
+            asm volatile(REP16("v_and_b32 %0, %0, %1\n v_or_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_and_or_b32 %3, %3, %0, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 30) {
+            asm volatile(REP16("v_max3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %1, %2, %3\n v_mad_u32_u24 %2, %2, %3, %0\n v_add3_u32 %3, %3, %0, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 31) {
+            asm volatile(REP16("v_cmp_lt_f32_e32 vcc, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");
+        } else if (KIND == 32) {
+            asm volatile(REP16("v_cndmask_b32 %0, %0, %1, %4\n v_add_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_add_f32 %3, %3, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(m));
+        } else if (KIND == 33) {
+            asm volatile(REP16("v_cndmask_b32 %0, %0, %1, %4\n v_add_f32 %1, %1, %2\n v_cndmask_b32 %2, %2, %3, %4\n v_add_f32 %3, %3, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(m));
+        } else if (KIND == 34) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32 %1, %1, %2\n"
+                               "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32 %3, %3, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 35) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32 %1, %1, %2, %4\n"
+                               "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cndmask_b32 %3, %3, %1, %4\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(m));
+        } else if (KIND == 36) {
+            asm volatile(REP16("v_exp_f32 %0, %0\n v_add_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_add_f32 %3, %3, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 37) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32 %1, %1, %2\n"
+                               "v_add_f32 %2, %2, %3\n v_add_f32 %3, %3, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 38) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32 %0, %0, %1\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 39) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 40) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\ns_nop 0\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 41) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32 %0, %0, %1\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %0\nv_add_f32 %0, %0, %1\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 42) {
+            asm volatile(REP16("v_exp_f32 %0, %0\n s_nop 0\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 43) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\ns_nop 1\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 44) {
+            asm volatile(REP16("v_add_f32 %1, %1, %2\nv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\ns_nop 0\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 45) {
+            asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\ns_nop 0\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 46) {
+            asm volatile(REP16("v_rcp_f32 %0, %0\n s_nop 0\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 47) {
+            asm volatile(REP16("v_exp_f32 %0, %0\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\nv_add_f32 %1, %1, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + e + f + g + h + (float)mi + (float)(m & 1);
 }
 
 template <int KIND>
-void run(const char* name, float* out, int wgs)
+void run(const char* name, float* out, int wgs, int per_rep = 4)
 {
-    const int iters = 2000;  // 64 instructions per iteration per wave
+    const int iters = 2000;  // 16 * per_rep instructions per iteration per wave
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<KIND>, dim3(wgs), dim3(256), 0, 0, out, 10);
@@ -132,7 +185,7 @@ void run(const char* name, float* out, int wgs)
     hipEventElapsedTime(&ms, e0, e1);
     // every SIMD runs wgs*4/1024 waves one after / beside another
     const double waves_per_simd = wgs * 4.0 / 1024.0;
-    const double cyc = ms * 1e-3 * 2.4e9 / (iters * 64.0 * waves_per_simd);
+    const double cyc = ms * 1e-3 * 2.4e9 / (iters * 16.0 * per_rep * waves_per_simd);
     printf("%-28s %8.3f ms  %6.2f cycles per wave-instruction per SIMD (at 2.4 GHz, %g waves/SIMD)\n", name, ms, cyc, waves_per_simd);
 }
 
@@ -169,6 +222,26 @@ int main()
         run<25>("inline constants 0.5/2/1/-1", out, wgs);
         run<26>("rndne/cvt/lshl_add/cvt", out, wgs);
         run<27>("4 v_mul + 2 s_nop 0 (per 4 instr)", out, wgs);
+        run<28>("v_bfi_b32 (vgpr mask select)", out, wgs);
+        run<29>("and/or/xor/and_or", out, wgs);
+        run<30>("max3/min3/mad_u32_u24/add3", out, wgs);
+        run<31>("1 v_cmp + 3 v_add", out, wgs);
+        run<32>("1 cndmask + 3 add", out, wgs);
+        run<33>("2 cndmask + 2 add", out, wgs);
+        run<34>("2 dpp + 2 add", out, wgs);
+        run<35>("2 dpp + 2 cndmask", out, wgs);
+        run<36>("1 exp + 3 add", out, wgs);
+        run<37>("1 dpp + 3 add", out, wgs);
+        run<38>("4 dpp + 4 add, grouped", out, wgs, 8);
+        run<39>("2 dpp + 2 add, grouped", out, wgs, 4);
+        run<40>("1 dpp + s_nop + 3 add", out, wgs, 4);
+        run<41>("8 dpp + 8 add, grouped", out, wgs, 16);
+        run<42>("1 exp + s_nop + 3 add", out, wgs, 4);
+        run<43>("1 dpp + s_nop 1 + 3 add", out, wgs, 4);
+        run<44>("add, dpp, s_nop, 2 add", out, wgs, 4);
+        run<45>("2 dpp + s_nop + 2 add", out, wgs, 4);
+        run<46>("1 rcp + s_nop + 3 add", out, wgs, 4);
+        run<47>("1 exp + 7 add", out, wgs, 8);
     }
     return 0;
 }
