@@ -40,7 +40,7 @@ class _L1SSIM(torch.autograd.Function):
                        "gsr_loss_forward")
         ctx.save_for_backward(a, b, scratch)
         ctx.lam, ctx.which, ctx.shape = lam, which, img1.shape
-        return out[which].clone()
+        return out[which]
 
     @staticmethod
     def backward(ctx, grad):
