@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -52,8 +52,9 @@ PROTOTYPES = {
     "gsr_compact_rows": (c_int, [c_int, c_void_p, c_void_p, c_size, c_int, c_void_p, c_void_p]),
     "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_loss_scratch_bytes": (c_size, [c_int, c_int, c_int]),
-    "gsr_loss_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p]),
-    "gsr_loss_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p, c_void_p]),
+    "gsr_loss_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p]),
+    "gsr_loss_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
     "gsr_knn_scratch_bytes": (c_size, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),

@@ -432,27 +432,28 @@ size_t gsr_loss_scratch_bytes(int C, int H, int W)
     return gsr_loss_scratch_layout(C, H, W, &a, &b);
 }
 
-int gsr_loss_forward(int C, int H, int W, const float* img1, const float* img2, float lambda_dssim, void* scratch,
-                     size_t scratch_bytes, float* out3, void* stream)
+int gsr_loss_forward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda_dssim,
+                     void* scratch, size_t scratch_bytes, float* out3, void* stream)
 {
     if (C <= 0 || H <= 0 || W <= 0) return fail(-1, "invalid image size");
     if (!img1 || !img2 || !scratch || !out3) return fail(-1, "NULL required pointer");
     size_t mo, po;
     if (scratch_bytes < gsr_loss_scratch_layout(C, H, W, &mo, &po)) return fail(-3, "loss scratch too small");
-    gsr_launch_loss_forward(C, H, W, img1, img2, lambda_dssim, (float*)((char*)scratch + mo), (float*)((char*)scratch + po), out3,
+    gsr_launch_loss_forward(C, H, W, img1, img2, img_l1, lambda_dssim, (float*)((char*)scratch + mo), (float*)((char*)scratch + po), out3,
                             (hipStream_t)stream);
     return check_hip("loss_forward");
 }
 
-int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2, float lambda_dssim, const void* scratch,
-                      size_t scratch_bytes, const float* grad_loss, float* dL_dimg1, void* stream)
+int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda_dssim,
+                      const void* scratch, size_t scratch_bytes, const float* grad_loss, float* dL_dimg1, float* dL_dimg_l1,
+                      void* stream)
 {
     if (C <= 0 || H <= 0 || W <= 0) return fail(-1, "invalid image size");
-    if (!img1 || !img2 || !scratch || !dL_dimg1) return fail(-1, "NULL required pointer");
+    if (!img1 || !img2 || !scratch || !dL_dimg1 || (img_l1 && !dL_dimg_l1)) return fail(-1, "NULL required pointer");
     size_t mo, po;
     if (scratch_bytes < gsr_loss_scratch_layout(C, H, W, &mo, &po)) return fail(-3, "loss scratch too small");
-    gsr_launch_loss_backward(C, H, W, img1, img2, (const float*)((const char*)scratch + mo), lambda_dssim, grad_loss, dL_dimg1,
-                             (hipStream_t)stream);
+    gsr_launch_loss_backward(C, H, W, img1, img2, img_l1, (const float*)((const char*)scratch + mo), lambda_dssim, grad_loss,
+                             dL_dimg1, dL_dimg_l1, (hipStream_t)stream);
     return check_hip("loss_backward");
 }
 

@@ -159,10 +159,10 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s);
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 size_t gsr_loss_scratch_layout(int C, int H, int W, size_t* maps_off, size_t* partials_off);
-void gsr_launch_loss_forward(int C, int H, int W, const float* img1, const float* img2, float lambda, float* maps, float* partials,
-                             float* out3, hipStream_t s);
-void gsr_launch_loss_backward(int C, int H, int W, const float* img1, const float* img2, const float* maps, float lambda,
-                              const float* grad_loss, float* dL_dimg1, hipStream_t s);
+void gsr_launch_loss_forward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda,
+                             float* maps, float* partials, float* out3, hipStream_t s);
+void gsr_launch_loss_backward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, const float* maps,
+                              float lambda, const float* grad_loss, float* dL_dimg1, float* dL_dimg_l1, hipStream_t s);
 
 struct GsrAdamTensorHost {  // = gsr_adam_tensor of the C ABI
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq;

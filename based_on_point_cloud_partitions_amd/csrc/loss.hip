@@ -34,8 +34,8 @@ constexpr int SH = TB + 1;           // LDS row stride of the horizontally filte
 // loss is compared with the reference at 1e-6, not bit for bit).
 template <int TBY>
 __global__ void __launch_bounds__(256) ssim_forward_kernel(int C, int H, int W, const float* __restrict__ img1,
-                                                           const float* __restrict__ img2, float* __restrict__ maps,
-                                                           float* __restrict__ partials)
+                                                           const float* __restrict__ img2, const float* __restrict__ img_l1,
+                                                           float* __restrict__ maps, float* __restrict__ partials)
 {
     constexpr int TINY = TBY + 2 * HALO, RPT = TBY / 8;
     __shared__ float s_x[TINY][SX], s_y[TINY][SX];
@@ -114,7 +114,9 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(int C, int H, int W, 
             maps[CP + id] = -(A * B) * (inv * __builtin_amdgcn_rcpf(D));                                     // d m / d E[x^2] = -m / D
             maps[2 * CP + id] = 2.f * A * inv;                                                               // d m / d E[xy]
             m_sum += m;
-            l1_sum += fabsf(s_x[rg + j + HALO][tx + HALO] - s_y[rg + j + HALO][tx + HALO]);
+            // L1 on the rendered image itself, or on a separate image (the appearance-decoupled one of train.py:112-116)
+            const float xl = img_l1 ? img_l1[id] : s_x[rg + j + HALO][tx + HALO];
+            l1_sum += fabsf(xl - s_y[rg + j + HALO][tx + HALO]);
         }
     }
 #pragma unroll
@@ -152,8 +154,9 @@ __global__ void __launch_bounds__(1024) loss_finalize_kernel(int nblocks, const 
 template <int TBY>
 __global__ void __launch_bounds__(256) ssim_backward_kernel(int C, int H, int W, const float* __restrict__ img1,
                                                             const float* __restrict__ img2, const float* __restrict__ maps,
-                                                            float lambda, float invN, const float* __restrict__ grad_loss,
-                                                            float* __restrict__ dL_dimg1)
+                                                            const float* __restrict__ img_l1, float lambda, float invN,
+                                                            const float* __restrict__ grad_loss, float* __restrict__ dL_dimg1,
+                                                            float* __restrict__ dL_dimg_l1)
 {
     constexpr int TINY = TBY + 2 * HALO, RPT = TBY / 8;
     __shared__ float s_m[3][TINY][SX];
@@ -212,9 +215,16 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(int C, int H, int W,
         if (gx < W && gy < H) {
             const size_t id = (size_t)c * plane + (size_t)gy * W + gx;
             const float x = img1[id], y = img2[id];
-            const float d = x - y;
+            const float d = (img_l1 ? img_l1[id] : x) - y;
             const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
-            dL_dimg1[id] = g * ((-lambda * invN) * (acc[j][0] + 2.f * x * acc[j][1] + y * acc[j][2]) + ((1.0f - lambda) * invN) * sgn);
+            const float g_ssim = (-lambda * invN) * (acc[j][0] + 2.f * x * acc[j][1] + y * acc[j][2]);
+            const float g_l1 = ((1.0f - lambda) * invN) * sgn;
+            if (img_l1) {
+                dL_dimg1[id] = g * g_ssim;
+                dL_dimg_l1[id] = g * g_l1;
+            } else {
+                dL_dimg1[id] = g * (g_ssim + g_l1);
+            }
         }
     }
 }
@@ -231,26 +241,26 @@ size_t gsr_loss_scratch_layout(int C, int H, int W, size_t* maps_off, size_t* pa
     return o;
 }
 
-void gsr_launch_loss_forward(int C, int H, int W, const float* img1, const float* img2, float lambda, float* maps, float* partials,
-                             float* out3, hipStream_t s)
+void gsr_launch_loss_forward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda,
+                             float* maps, float* partials, float* out3, hipStream_t s)
 {
     const int tby = gsr_variant("LOSS_TBY", 32) == 16 ? 16 : 32;
     const dim3 grid((W + TB - 1) / TB, (H + tby - 1) / tby, C);
-    if (tby == 16) hipLaunchKernelGGL(ssim_forward_kernel<16>, grid, dim3(256), 0, s, C, H, W, img1, img2, maps, partials);
-    else hipLaunchKernelGGL(ssim_forward_kernel<32>, grid, dim3(256), 0, s, C, H, W, img1, img2, maps, partials);
+    if (tby == 16) hipLaunchKernelGGL(ssim_forward_kernel<16>, grid, dim3(256), 0, s, C, H, W, img1, img2, img_l1, maps, partials);
+    else hipLaunchKernelGGL(ssim_forward_kernel<32>, grid, dim3(256), 0, s, C, H, W, img1, img2, img_l1, maps, partials);
     const int nblk = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, nblk, partials, lambda, 1.0f / ((float)C * H * W), out3);
 }
 
-void gsr_launch_loss_backward(int C, int H, int W, const float* img1, const float* img2, const float* maps, float lambda,
-                              const float* grad_loss, float* dL_dimg1, hipStream_t s)
+void gsr_launch_loss_backward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, const float* maps,
+                              float lambda, const float* grad_loss, float* dL_dimg1, float* dL_dimg_l1, hipStream_t s)
 {
     const int tby = gsr_variant("LOSS_TBY", 32) == 16 ? 16 : 32;
     const dim3 grid((W + TB - 1) / TB, (H + tby - 1) / tby, C);
     if (tby == 16)
-        hipLaunchKernelGGL(ssim_backward_kernel<16>, grid, dim3(256), 0, s, C, H, W, img1, img2, maps, lambda, 1.0f / ((float)C * H * W),
-                           grad_loss, dL_dimg1);
+        hipLaunchKernelGGL(ssim_backward_kernel<16>, grid, dim3(256), 0, s, C, H, W, img1, img2, maps, img_l1, lambda,
+                           1.0f / ((float)C * H * W), grad_loss, dL_dimg1, dL_dimg_l1);
     else
-        hipLaunchKernelGGL(ssim_backward_kernel<32>, grid, dim3(256), 0, s, C, H, W, img1, img2, maps, lambda, 1.0f / ((float)C * H * W),
-                           grad_loss, dL_dimg1);
+        hipLaunchKernelGGL(ssim_backward_kernel<32>, grid, dim3(256), 0, s, C, H, W, img1, img2, maps, img_l1, lambda,
+                           1.0f / ((float)C * H * W), grad_loss, dL_dimg1, dL_dimg_l1);
 }

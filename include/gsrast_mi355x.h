@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -115,16 +115,19 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 size_t gsr_knn_scratch_bytes(int P);
 int gsr_knn_mean_dist2(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, void* stream);
 
-/* Loss block of the training step: loss = (1 - lambda) * L1(img1, img2) + lambda * (1 - SSIM(img1, img2)),
- * the reference's utils/loss_utils.py:17-18,23-63 combined as in train.py:116-117 (11-tap Gaussian window, sigma 1.5, zero
- * padding, mean over C*H*W).  Images are [C][H][W] float32 on the device.  gsr_loss_forward writes out3 = {loss, L1, SSIM}
- * (device) and keeps the per-pixel partial derivatives in `scratch` (gsr_loss_scratch_bytes); gsr_loss_backward turns them
- * into dL/dimg1 scaled by *grad_loss (device scalar, NULL = 1), i.e. the dL/dcolor the rasterizer's backward consumes. */
+/* Loss block of the training step: loss = (1 - lambda) * L1(img_l1, img2) + lambda * (1 - SSIM(img1, img2)),
+ * the reference's utils/loss_utils.py:17-18,23-63 combined as in train.py:112-117 (11-tap Gaussian window, sigma 1.5, zero
+ * padding, mean over C*H*W).  img1 = rendered image, img2 = ground truth; img_l1 = the image the L1 term is taken on:
+ * NULL means img1 (plain 3DGS), the reference's train.py passes the appearance-decoupled image there (train.py:112,116).
+ * Images are [C][H][W] float32 on the device.  gsr_loss_forward writes out3 = {loss, L1, SSIM} (device) and keeps the per-pixel
+ * partial derivatives in `scratch` (gsr_loss_scratch_bytes); gsr_loss_backward turns them into dL/dimg1 (the dL/dcolor the
+ * rasterizer's backward consumes) and, when img_l1 is given, dL/dimg_l1, both scaled by *grad_loss (device scalar, NULL = 1). */
 size_t gsr_loss_scratch_bytes(int C, int H, int W);
-int gsr_loss_forward(int C, int H, int W, const float* img1, const float* img2, float lambda_dssim, void* scratch,
-                     size_t scratch_bytes, float* out3, void* stream);
-int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2, float lambda_dssim, const void* scratch,
-                      size_t scratch_bytes, const float* grad_loss, float* dL_dimg1, void* stream);
+int gsr_loss_forward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda_dssim,
+                     void* scratch, size_t scratch_bytes, float* out3, void* stream);
+int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda_dssim,
+                      const void* scratch, size_t scratch_bytes, const float* grad_loss, float* dL_dimg1, float* dL_dimg_l1,
+                      void* stream);
 
 /* Optimizer step of the training loop: torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of
  * scene/gaussian_model.py:164-175 / train.py:155-157 for ALL parameter tensors in one launch -- dense Adam, weight_decay = 0,

@@ -97,6 +97,29 @@ def ref_loss():
     np.savez_compressed(os.path.join(HERE, "ref_loss.npz"), **out)
 
 
+def ref_loss_decoupled():
+    """The reference's train.py:112-117 form of the loss: L1 on the appearance-decoupled image, SSIM on the rendered one,
+    evaluated with its own utils/loss_utils.py; gradients w.r.t. both images."""
+    lu = _load("ref_loss_utils", "utils/loss_utils.py")
+    out = {}
+    g = torch.Generator().manual_seed(78)
+    k = 0
+    for (C, H, W), lam in [((3, 41, 67), 0.2), ((3, 64, 96), 0.35)]:
+        gt = torch.rand(C, H, W, generator=g)
+        img = (gt + 0.15 * torch.randn(C, H, W, generator=g)).clamp(0, 1.2).requires_grad_(True)
+        dec = (img.detach() * (0.8 + 0.4 * torch.rand(C, H, W, generator=g))).requires_grad_(True)  # mapping_image * image
+        Ll1 = lu.l1_loss(dec, gt)
+        s = lu.ssim(img, gt)
+        loss = (1.0 - lam) * Ll1 + lam * (1.0 - s)
+        loss.backward()
+        out[f"img{k}"] = img.detach().numpy(); out[f"dec{k}"] = dec.detach().numpy(); out[f"gt{k}"] = gt.numpy()
+        out[f"res{k}"] = np.array([loss.item(), Ll1.item(), s.item(), lam], dtype=np.float64)
+        out[f"grad_img{k}"] = img.grad.numpy(); out[f"grad_dec{k}"] = dec.grad.numpy()
+        k += 1
+    out["n"] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, "ref_loss_decoupled.npz"), **out)
+
+
 def _h(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
@@ -138,6 +161,7 @@ if __name__ == "__main__":
     ref_sh()
     ref_cameras()
     ref_loss()
+    ref_loss_decoupled()
     oracle_snapshot()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
