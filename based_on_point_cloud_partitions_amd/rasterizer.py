@@ -17,8 +17,18 @@ from . import _lib
 NUM_CHANNELS = 3  # cuda_rasterizer/config.h:14
 
 # Largest num_rendered seen per (device, P, W, H): sizes the binning buffer BEFORE the forward so that both phases run
-# in one native call (gsr_forward); a too-small guess only costs a second call.
+# in one native call (gsr_forward); a too-small guess only costs a second call.  Densification changes P every few
+# hundred iterations, so the table is kept small (oldest keys dropped).
 _R_SEEN = {}
+_R_SEEN_MAX = 64
+
+
+def _remember_rendered(key, rendered):
+    if rendered > _R_SEEN.get(key, 0):
+        _R_SEEN.pop(key, None)
+        _R_SEEN[key] = rendered  # most recently raised key last
+        while len(_R_SEEN) > _R_SEEN_MAX:
+            _R_SEEN.pop(next(iter(_R_SEEN)))
 
 
 def _ptr(t):
@@ -98,8 +108,7 @@ def rasterize_gaussians_forward(background, means3D, colors, opacity, scales, ro
                 _lib.check(lib.gsr_forward_render(
                     P, rendered, W, H, _ptr(bg), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer), binningBuffer.numel(),
                     _ptr(imgBuffer), imgBuffer.numel(), _ptr(out_color), s), "gsr_forward_render")
-            if rendered > guess:
-                _R_SEEN[key] = rendered
+            _remember_rendered(key, rendered)
             if debug:
                 torch.cuda.synchronize(dev)  # CHECK_CUDA(..., debug), auxiliary.h:166-173
     return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer

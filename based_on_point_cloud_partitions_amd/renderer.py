@@ -17,8 +17,8 @@ import math
 import torch
 
 from . import _lib
-from .rasterizer import (NUM_CHANNELS, _R_SEEN, GaussianRasterizationSettings, GaussianRasterizer, _prep, _ptr, _require_hip,
-                         _stream)
+from .rasterizer import (NUM_CHANNELS, _R_SEEN, GaussianRasterizationSettings, GaussianRasterizer, _prep, _ptr, _remember_rendered,
+                         _require_hip, _stream)
 
 
 def rasterize_gaussian_params_forward(background, xyz, features_dc, features_rest, opacity, scaling, rotation, scale_modifier,
@@ -72,8 +72,7 @@ def rasterize_gaussian_params_forward(background, xyz, features_dc, features_res
                 _lib.check(lib.gsr_forward_render(
                     P, rendered, W, H, _ptr(bg), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer), binningBuffer.numel(),
                     _ptr(imgBuffer), imgBuffer.numel(), _ptr(out_color), s), "gsr_forward_render")
-            if rendered > guess:
-                _R_SEEN[key] = rendered
+            _remember_rendered(key, rendered)
             if debug:
                 torch.cuda.synchronize(dev)
     return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer
