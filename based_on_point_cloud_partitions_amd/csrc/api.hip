@@ -235,18 +235,19 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
             {   // per-Gaussian instance offsets only (needed by the backward's gradient-row addressing)
                 StageTimer t(GSR_STAGE_EMIT, s);
                 gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
-                                (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets), nullptr, nullptr, s);
+                                (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets), nullptr, nullptr,
+                                (uint32_t*)(b + B.band), s);
             }
             StageTimer t(GSR_STAGE_SORT, s);
             gsr_launch_tile_binning(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
-                                    (uint32_t*)(b + B.order), ranges, ka, va,
+                                    (uint32_t*)(b + B.order), ranges, (uint32_t*)(b + B.band), ka, va,
                                     gsr_variant("KEYS", 0) ? kb : nullptr, s);
             point_list = va;
         } else {
         {
             StageTimer t(GSR_STAGE_EMIT, s);
             gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
-                            (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets), ka, va, s);
+                            (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets), ka, va, nullptr, s);
         }
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));  // rasterizer_impl.cu:300-308
         int in_b;

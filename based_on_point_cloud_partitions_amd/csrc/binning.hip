@@ -192,6 +192,171 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Banded variant of (1)-(3).  With slices that cover the whole image, a slice contributes only ~7 entries to any one tile:
+// the scatter then writes 8-byte pairs into ~60-byte runs spread over all tile segments, every store a partial line
+// (measured: 244 MB of write traffic for 30 MB of pairs).  Here the tile rows are cut into NB horizontal bands and the
+// visible Gaussians are first partitioned into per-band id lists (a Gaussian whose rectangle crosses a band boundary is
+// listed in each band it touches).  A slice then works on ONE band: its runs per tile are NB times longer, the
+// [slice][tile] table shrinks NB-fold (band tiles only), and the LDS histograms cover a band instead of the image.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int BAND_SLICES = 64;   // slices per band
+constexpr int NB_MAX = GSR_BAND_COUNTERS;  // bands
+
+struct BandGeom { int gx, gy, T, nb, bh, tmax; };  // bh = tile rows per band, tmax = bh * gx
+
+__device__ __forceinline__ void band_slice_range(const uint32_t* __restrict__ band_count, int b, int sidx, uint32_t& first, uint32_t& last)
+{
+    const uint32_t n = band_count[b];
+    const uint32_t per = (n + BAND_SLICES - 1) / BAND_SLICES;
+    first = min(n, (uint32_t)sidx * per);
+    last = min(n, first + per);
+}
+
+__global__ void __launch_bounds__(SLICE_THREADS) tile_count_banded_kernel(int P, BandGeom G, const float* __restrict__ splat,
+                                                                           const uint32_t* __restrict__ band_count,
+                                                                           const uint32_t* __restrict__ band_list, uint32_t* __restrict__ table)
+{
+    extern __shared__ uint32_t s_hist[];
+    const int b = blockIdx.x / BAND_SLICES, sidx = blockIdx.x % BAND_SLICES;
+    const uint32_t row0 = (uint32_t)(b * G.bh), row1 = min((uint32_t)G.gy, row0 + (uint32_t)G.bh);
+    const int tn = (int)(row1 - row0) * G.gx;
+    for (int t = threadIdx.x; t < tn; t += SLICE_THREADS) s_hist[t] = 0;
+    __syncthreads();
+    uint32_t first, last;
+    band_slice_range(band_count, b, sidx, first, last);
+    for (uint32_t i = first + threadIdx.x; i < last; i += SLICE_THREADS) {
+        const SliceRect r = load_rect(splat, (int)band_list[(size_t)b * P + i], G.gx, G.gy);
+        const uint32_t y0 = max(r.mny, row0), y1 = min(r.mxy, row1);
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = r.mnx; x < r.mxx; x++) atomicAdd(&s_hist[(y - row0) * (uint32_t)G.gx + x], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * G.tmax;
+    for (int t = threadIdx.x; t < tn; t += SLICE_THREADS) row[t] = s_hist[t];
+}
+
+// per band and tile: exclusive prefix over the band's slices (in place) and the tile total; blockIdx.y = band
+__global__ void __launch_bounds__(256) tile_colscan_banded_kernel(BandGeom G, uint32_t* __restrict__ table, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t part[8][32];
+    const int b = blockIdx.y;
+    const int row0 = b * G.bh, row1 = min(G.gy, row0 + G.bh);
+    const int tn = (row1 - row0) * G.gx;
+    const int tl = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tl;
+    if (blockIdx.x * 32 >= tn) return;
+    constexpr int per = BAND_SLICES / 8;
+    uint32_t* col = table + (size_t)b * BAND_SLICES * G.tmax + t;
+    uint32_t sum = 0;
+    if (t < tn) {
+#pragma unroll
+        for (int k = 0; k < per; k++) sum += col[(size_t)(sg * per + k) * G.tmax];
+    }
+    part[sg][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int g = 0; g < sg; g++) run += part[g][tl];
+    if (t < tn) {
+#pragma unroll
+        for (int k = 0; k < per; k++) {
+            uint32_t* e = col + (size_t)(sg * per + k) * G.tmax;
+            const uint32_t c = *e;
+            *e = run;
+            run += c;
+        }
+        if (sg == 7) totals[row0 * G.gx + t] = run;
+    }
+}
+
+__global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_banded_kernel(int P, BandGeom G, const float* __restrict__ splat,
+                                                                             const uint32_t* __restrict__ band_count,
+                                                                             const uint32_t* __restrict__ band_list,
+                                                                             const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
+                                                                             uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                                             uint2* __restrict__ bins)
+{
+    extern __shared__ uint32_t s_cur[];
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t cls_cnt[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = G.T;
+    if (blockIdx.x == (uint32_t)(G.nb * BAND_SLICES)) {  // one extra workgroup: launch order of the blend kernels (see tile_scatter_kernel)
+        if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += SLICE_THREADS) atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int c0 = 255 - 4 * (int)threadIdx.x;
+            const uint32_t n0 = cls_cnt[c0], n1 = cls_cnt[c0 - 1], n2 = cls_cnt[c0 - 2], n3 = cls_cnt[c0 - 3];
+            const uint32_t tsum = n0 + n1 + n2 + n3;
+            uint32_t incl = tsum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(incl, off, 64);
+                if ((int)threadIdx.x >= off) incl += u;
+            }
+            const uint32_t bb = incl - tsum;
+            cls_cnt[c0] = bb; cls_cnt[c0 - 1] = bb + n0; cls_cnt[c0 - 2] = bb + n0 + n1; cls_cnt[c0 - 3] = bb + n0 + n1 + n2;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += SLICE_THREADS) order[atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u)] = (uint32_t)i;
+        return;
+    }
+    const int b = blockIdx.x / BAND_SLICES, sidx = blockIdx.x % BAND_SLICES;
+    const uint32_t row0 = (uint32_t)(b * G.bh), row1 = min((uint32_t)G.gy, row0 + (uint32_t)G.bh);
+    const int t0 = (int)row0 * G.gx, tn = (int)(row1 - row0) * G.gx;
+    const uint32_t* row = table + (size_t)blockIdx.x * G.tmax;
+    // exclusive scan of ALL tile totals (tile starts); the band's tiles get their cursor, workgroup 0 stores ranges[]
+    constexpr int EPT = 8;
+    uint32_t chunk_base = 0;
+    for (int tbase = 0; tbase < T; tbase += SLICE_THREADS * EPT) {
+        const int i0 = tbase + (int)threadIdx.x * EPT;
+        uint32_t v[EPT], tsum = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) { v[e] = i0 + e < T ? totals[i0 + e] : 0u; tsum += v[e]; }
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += u;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, chunk_total = 0;
+#pragma unroll
+        for (int w = 0; w < SLICE_THREADS / 64; w++) { if (w < wave) wbase += wtot[w]; chunk_total += wtot[w]; }
+        uint32_t st = chunk_base + wbase + incl - tsum;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int t = i0 + e;
+            if (t < T) {
+                const int lt = t - t0;
+                if (lt >= 0 && lt < tn) s_cur[lt] = st + row[lt];
+                if (blockIdx.x == 0) {
+                    ranges[2 * t] = v[e] ? st : 0u;
+                    ranges[2 * t + 1] = v[e] ? st + v[e] : 0u;
+                }
+            }
+            st += v[e];
+        }
+        chunk_base += chunk_total;
+        __syncthreads();
+    }
+    uint32_t first, last;
+    band_slice_range(band_count, b, sidx, first, last);
+    for (uint32_t i = first + threadIdx.x; i < last; i += SLICE_THREADS) {
+        const uint32_t idx = band_list[(size_t)b * P + i];
+        const SliceRect r = load_rect(splat, (int)idx, G.gx, G.gy);
+        const uint32_t y0 = max(r.mny, row0), y1 = min(r.mxy, row1);
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = r.mnx; x < r.mxx; x++) {
+                const uint32_t slot = atomicAdd(&s_cur[(y - row0) * (uint32_t)G.gx + x], 1u);
+                bins[slot] = make_uint2(idx, r.dbits);  // little-endian u64 = depth << 32 | id
+            }
+    }
+}
+
 // Normalized bitonic network on n keys held in `a` (LDS or HBM), virtually padded with +inf up to N = pow2 >= n.
 // Every comparator is ascending (lo < hi), so a comparator whose upper index is >= n is a no-op.
 // Comparator i of a stage is handled by wave (i / (N/2 / waves)): each of the `waves` active waves owns one contiguous
@@ -377,7 +542,7 @@ __global__ void __launch_bounds__(256) tile_sort_small_kernel(const uint32_t* __
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
     const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const uint32_t n = r1 - r0;
-    if (n == 0 || n > BUCKET_CAP) return;  // empty, or handled by tile_sort_mid_kernel / tile_sort_large_kernel
+    if (n == 0 || n > BUCKET_CAP) return;  // empty, or handled by tile_sort_mid_kernel
     uint32_t N = 1;
     while (N < n) N <<= 1;
     if (N <= 512) bucket_sort_tile<2, 256, BUCKET_CAP>(L, tile, r0, n, N, bins, point_list, keys_sorted);
@@ -385,11 +550,11 @@ __global__ void __launch_bounds__(256) tile_sort_small_kernel(const uint32_t* __
     else bucket_sort_tile<8, 256, BUCKET_CAP>(L, tile, r0, n, N, bins, point_list, keys_sorted);
 }
 
-// (5a') lists of 2049..8192 entries (dense scenes: the 2M-Gaussian configuration has a mean list length of ~1900): the same
+// (5a') lists of more than 2048 entries: up to 8192 (dense scenes: the 2M-Gaussian configuration has a mean list length of ~1900): the same
 // bucket sort with 1024 threads and 96 KB of LDS; the bitonic network took 0.8 ms per frame there.
 __global__ void __launch_bounds__(1024) tile_sort_mid_kernel(int T, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
-                                                             const unsigned long long* __restrict__ bins,
+                                                             const unsigned long long* bins,
                                                              uint32_t* __restrict__ point_list,
                                                              unsigned long long* __restrict__ keys_sorted)
 {
@@ -402,39 +567,22 @@ __global__ void __launch_bounds__(1024) tile_sort_mid_kernel(int T, const uint32
         const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
         const uint32_t n = r1 - r0;
         if (n < 2040) break;
-        if (n <= BUCKET_CAP || n > BUCKET_CAP_MID) continue;
+        if (n <= BUCKET_CAP) continue;
         uint32_t N = 1;
         while (N < n) N <<= 1;
-        if (N <= 4096) bucket_sort_tile<4, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+        if (n > BUCKET_CAP_MID) {
+            // rare: list longer than the LDS budget -> normalized bitonic network in place in HBM (workgroup-scope visibility
+            // via __syncthreads; the network keeps waves 0-3 busy, the others only join the barriers)
+            unsigned long long* seg = const_cast<unsigned long long*>(bins) + r0;
+            bitonic_sort_block<false>(seg, n, N);
+            for (uint32_t k = threadIdx.x; k < n; k += 1024) {
+                const unsigned long long key = seg[k];
+                point_list[r0 + k] = (uint32_t)key;
+                if (keys_sorted) keys_sorted[r0 + k] = ((unsigned long long)tile << 32) | (key >> 32);
+            }
+        } else if (N <= 4096) bucket_sort_tile<4, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
         else bucket_sort_tile<8, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
         __syncthreads();  // the LDS image is reused by the next list
-    }
-}
-
-// (5b) one workgroup per tile, lists longer than BUCKET_CAP: bitonic network in LDS (<= SORT_CAP) or in place in HBM.
-__global__ void __launch_bounds__(256) tile_sort_large_kernel(int T, const uint32_t* __restrict__ order,
-                                                              const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ bins,
-                                                              uint32_t* __restrict__ point_list, unsigned long long* __restrict__ keys_sorted)
-{
-    for (int i = blockIdx.x; i < T; i += gridDim.x) {
-        const uint32_t tile = order[i];
-        const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
-        const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
-        const uint32_t n = r1 - r0;
-        if (n < 2040) break;  // see tile_sort_mid_kernel
-        if (n <= BUCKET_CAP_MID) continue;
-        uint32_t N = 1;
-        while (N < n) N <<= 1;
-        unsigned long long* seg = bins + r0;
-        // rare: list longer than the LDS budget -> normalized bitonic network in place in HBM (workgroup-scope visibility via
-        // __syncthreads)
-        bitonic_sort_block<false>(seg, n, N);
-        for (uint32_t k = threadIdx.x; k < n; k += 256) {
-            const unsigned long long key = seg[k];
-            point_list[r0 + k] = (uint32_t)key;
-            if (keys_sorted) keys_sorted[r0 + k] = ((unsigned long long)tile << 32) | (key >> 32);
-        }
-        __syncthreads();
     }
 }
 
@@ -453,22 +601,69 @@ int gsr_tile_slices(int P, int* gpb_out)
     return ns;
 }
 
+// Band geometry for an image: at least 8 bands, more when a band of the image would not fit the LDS histogram.
+static BandGeom band_geom(int gx, int gy)
+{
+    BandGeom G;
+    G.gx = gx; G.gy = gy; G.T = gx * gy;
+    int nb = gsr_variant("BANDS", 8);
+    if ((G.T + 8191) / 8192 > nb) nb = (G.T + 8191) / 8192;
+    if (nb > gy) nb = gy;
+    if (nb > NB_MAX) nb = NB_MAX;
+    if (nb < 1) nb = 1;
+    G.bh = (gy + nb - 1) / nb;
+    G.nb = (gy + G.bh - 1) / G.bh;
+    G.tmax = G.bh * gx;
+    return G;
+}
+
+bool gsr_band_geometry(int gx, int gy, int* nb, int* bh)
+{
+    const BandGeom G = band_geom(gx, gy);
+    *nb = G.nb; *bh = G.bh;
+    return gsr_variant("BIN", 2) == 2 && G.tmax <= TCHUNK && G.nb <= GSR_BAND_COUNTERS;
+}
+
+size_t gsr_band_table_bytes(int W, int H)
+{
+    const BandGeom G = band_geom((W + GSR_TILE_X - 1) / GSR_TILE_X, (H + GSR_TILE_Y - 1) / GSR_TILE_Y);
+    return (size_t)G.nb * BAND_SLICES * G.tmax * 4;
+}
+size_t gsr_band_list_bytes(int P, int W, int H)
+{
+    const BandGeom G = band_geom((W + GSR_TILE_X - 1) / GSR_TILE_X, (H + GSR_TILE_Y - 1) / GSR_TILE_Y);
+    return (size_t)G.nb * (size_t)(P > 0 ? P : 1) * 4 + GSR_BAND_COUNTERS * 4;  // id lists + the band counters in front
+}
+
 void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
-                             uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted, hipStream_t s)
+                             uint32_t* ranges, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
+                             hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int T = gx * gy;
-    int gpb;
-    const int ns = gsr_tile_slices(P, &gpb);
-    const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table);
-    hipLaunchKernelGGL(tile_colscan_kernel, dim3((T + 31) / 32), dim3(256), 0, s, T, ns, table, totals);
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table, totals, ranges,
-                       order, reinterpret_cast<uint2*>(bins));
+    const BandGeom G = band_geom(gx, gy);
+    int nb_, bh_;
+    if (band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_)) {
+        // the per-band id lists were filled by emit_keys_kernel (preprocess.hip)
+        const uint32_t* band_count = band_mem;
+        const uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
+        const size_t lds = (size_t)G.tmax * 4;
+        const int nwg = G.nb * BAND_SLICES;
+        hipLaunchKernelGGL(tile_count_banded_kernel, dim3(nwg), dim3(SLICE_THREADS), lds, s, P, G, splat, band_count, band_list, table);
+        hipLaunchKernelGGL(tile_colscan_banded_kernel, dim3((G.tmax + 31) / 32, G.nb), dim3(256), 0, s, G, table, totals);
+        hipLaunchKernelGGL(tile_scatter_banded_kernel, dim3(nwg + 1), dim3(SLICE_THREADS), lds, s, P, G, splat, band_count, band_list, table,
+                           totals, ranges, order, reinterpret_cast<uint2*>(bins));
+    } else {
+        int gpb;
+        const int ns = gsr_tile_slices(P, &gpb);
+        const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
+        hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table);
+        hipLaunchKernelGGL(tile_colscan_kernel, dim3((T + 31) / 32), dim3(256), 0, s, T, ns, table, totals);
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table, totals, ranges,
+                           order, reinterpret_cast<uint2*>(bins));
+    }
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<const unsigned long long*>(bins),
                        point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
     hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, order, ranges,
                        reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
-    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 64 ? T : 64), dim3(256), 0, s, T, order, ranges,
-                       reinterpret_cast<unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
 }

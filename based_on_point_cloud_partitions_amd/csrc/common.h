@@ -29,7 +29,7 @@ struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
 };
 struct BinLayout {
-    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, bytes;
+    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, band, bytes;
     uint32_t sort_blocks;
 };
 
@@ -71,6 +71,8 @@ static inline ImageLayout gsr_image_layout(int W, int H)
 #define GSR_SORT_TILE (GSR_SORT_THREADS * GSR_SORT_ITEMS)
 
 int gsr_tile_slices(int P, int* gpb_out);
+size_t gsr_band_table_bytes(int W, int H);
+size_t gsr_band_list_bytes(int P, int W, int H);
 
 static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
 {
@@ -88,9 +90,12 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
         const size_t ns = (size_t)gsr_tile_slices(P, &gpb);
         size_t t = (size_t)((W + GSR_TILE_X - 1) / GSR_TILE_X) * ((H + GSR_TILE_Y - 1) / GSR_TILE_Y);
         if (t == 0) t = 1;
-        L.table = o; o = gsr_align(o + ns * t * 4);
+        size_t tb = ns * t * 4;  // whole-image slices; the banded binning needs [bands * 64 slices][band tiles]
+        if (gsr_band_table_bytes(W, H) > tb) tb = gsr_band_table_bytes(W, H);
+        L.table = o; o = gsr_align(o + tb);
         L.totals = o; o = gsr_align(o + t * 4);
         L.order = o; o = gsr_align(o + t * 4);  // tiles by descending list length: launch order of the blend kernels
+        L.band = o; o = gsr_align(o + gsr_band_list_bytes(P, W, H));  // band counters + per-band Gaussian id lists
     }
     L.bytes = o;
     return L;
@@ -126,13 +131,17 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
                             unsigned long long* mailbox, uint32_t seq, hipStream_t s);
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                     uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s);
+                     uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, uint32_t* band_mem, hipStream_t s);
+#define GSR_BAND_COUNTERS 64  // band_mem = [64 counters][nb * P ids]
+// true (and the band count / height in tile rows) when the banded tile binning applies to this tile grid
+bool gsr_band_geometry(int gx, int gy, int* nb, int* bh);
 // returns 0 if the sorted pairs end in (ka,va), 1 if in (kb,vb)
 int gsr_launch_radix_sort(uint64_t* ka, uint64_t* kb, uint32_t* va, uint32_t* vb, uint32_t n, int end_bit,
                           uint32_t* hist_global, uint32_t* hist_blocks, uint32_t nblocks, hipStream_t s);
 static inline int gsr_sort_result_in_b(int end_bit) { return (((end_bit + 7) / 8) & 1); }
 void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
-                             uint32_t* ranges, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted, hipStream_t s);
+                             uint32_t* ranges, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
+                             hipStream_t s);
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,

@@ -100,7 +100,7 @@ def test_long_tile_lists_multiple_batches():
 
 
 def test_very_long_tile_lists_use_the_in_place_sort_path():
-    # > 8192 entries per tile: the per-tile sort leaves LDS and runs in place in HBM (tile_sort_large_kernel); lists of
+    # > 8192 entries per tile: the per-tile sort leaves LDS and runs in place in HBM; lists of
     # 2049..8192 entries take the 1024-thread bucket sort (tile_sort_mid_kernel), 1k..2k the larger 256-thread ones
     st, _ = _fwd_bwd(P=100_000, W=128, H=128, focal=80.0, seed=14, scale_lo=0.004, scale_hi=0.03)
     ln = st["ranges"][:, 1] - st["ranges"][:, 0]
