@@ -196,14 +196,37 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int 
 // Banded variant of (1)-(3).  With slices that cover the whole image, a slice contributes only ~7 entries to any one tile:
 // the scatter then writes 8-byte pairs into ~60-byte runs spread over all tile segments, every store a partial line
 // (measured: 244 MB of write traffic for 30 MB of pairs).  Here the tile rows are cut into NB horizontal bands and the
-// visible Gaussians are first partitioned into per-band id lists (a Gaussian whose rectangle crosses a band boundary is
-// listed in each band it touches).  A slice then works on ONE band: its runs per tile are NB times longer, the
+// visible Gaussians are first partitioned into per-band id lists (band_partition_kernel; a Gaussian whose rectangle crosses
+// a band boundary is listed in each band it touches).  A slice then works on ONE band: its runs per tile are NB times longer, the
 // [slice][tile] table shrinks NB-fold (band tiles only), and the LDS histograms cover a band instead of the image.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int BAND_SLICES = 64;   // slices per band
 constexpr int NB_MAX = GSR_BAND_COUNTERS;  // bands
 
 struct BandGeom { int gx, gy, T, nb, bh, tmax; };  // bh = tile rows per band, tmax = bh * gx
+
+__global__ void __launch_bounds__(SLICE_THREADS) band_partition_kernel(int P, BandGeom G, const float* __restrict__ splat,
+                                                                        uint32_t* __restrict__ band_count, uint32_t* __restrict__ band_list)
+{
+    __shared__ uint32_t cnt[NB_MAX], base[NB_MAX];
+    if (threadIdx.x < NB_MAX) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int idx = blockIdx.x * SLICE_THREADS + threadIdx.x;
+    int b0 = 0, b1 = -1;
+    if (idx < P) {
+        const SliceRect r = load_rect(splat, idx, G.gx, G.gy);
+        if (r.visible && r.mxy > r.mny && r.mxx > r.mnx) { b0 = (int)r.mny / G.bh; b1 = (int)(r.mxy - 1) / G.bh; }
+    }
+    for (int b = b0; b <= b1; b++) atomicAdd(&cnt[b], 1u);
+    __syncthreads();
+    if ((int)threadIdx.x < G.nb) {
+        const uint32_t c = cnt[threadIdx.x];
+        base[threadIdx.x] = c ? atomicAdd(&band_count[threadIdx.x], c) : 0u;
+        cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int b = b0; b <= b1; b++) band_list[(size_t)b * P + base[b] + atomicAdd(&cnt[b], 1u)] = (uint32_t)idx;
+}
 
 __device__ __forceinline__ void band_slice_range(const uint32_t* __restrict__ band_count, int b, int sidx, uint32_t& first, uint32_t& last)
 {
@@ -644,9 +667,11 @@ void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* 
     const BandGeom G = band_geom(gx, gy);
     int nb_, bh_;
     if (band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_)) {
-        // the per-band id lists were filled by emit_keys_kernel (preprocess.hip)
-        const uint32_t* band_count = band_mem;
-        const uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
+        // the band counters were zeroed by emit_keys_kernel (preprocess.hip), which runs right before this stage
+        uint32_t* band_count = band_mem;
+        uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
+        hipLaunchKernelGGL(band_partition_kernel, dim3((P + SLICE_THREADS - 1) / SLICE_THREADS), dim3(SLICE_THREADS), 0, s, P, G, splat,
+                           band_count, band_list);
         const size_t lds = (size_t)G.tmax * 4;
         const int nwg = G.nb * BAND_SLICES;
         hipLaunchKernelGGL(tile_count_banded_kernel, dim3(nwg), dim3(SLICE_THREADS), lds, s, P, G, splat, band_count, band_list, table);

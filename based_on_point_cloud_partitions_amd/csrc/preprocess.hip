@@ -249,18 +249,17 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(int n, const uint32_t
 // each Gaussian its first instance slot; keys are (tile id << 32) | depth bits, values the Gaussian index
 // (rasterizer_impl.cu:70-111).  Also records the inclusive offsets (point_offsets) and the exclusive
 // offset inside the splat record (used by the backward pass to address per-instance gradient rows).
-// With band_count != nullptr the kernel also partitions the visible Gaussians into the per-band id lists of the banded tile
-// binning (binning.hip): a Gaussian is appended to every band of `bh` tile rows its rectangle touches (workgroup-local
-// count in LDS, one global reservation per band and workgroup).
+// With band_count != nullptr workgroup 0 also zeroes the band counters of the banded tile binning (binning.hip), which the
+// next kernel fills with atomics -- a memset launch between the two would cost more than this store.
 __global__ void __launch_bounds__(256) emit_keys_kernel(int P, int gx, int gy, float* __restrict__ splat,
                                                         const uint32_t* __restrict__ tiles_touched,
                                                         const uint32_t* __restrict__ block_offsets,
                                                         uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals, int nb, int bh, uint32_t* __restrict__ band_count,
-                                                        uint32_t* __restrict__ band_list)
+                                                        uint32_t* __restrict__ vals, uint32_t* __restrict__ band_count)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (band_count && blockIdx.x == 0 && threadIdx.x < GSR_BAND_COUNTERS) band_count[threadIdx.x] = 0;
     const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
     uint32_t incl = n;
 #pragma unroll
@@ -269,38 +268,23 @@ __global__ void __launch_bounds__(256) emit_keys_kernel(int P, int gx, int gy, f
         if (lane >= off) incl += t;
     }
     __shared__ uint32_t wtot[4];
-    __shared__ uint32_t bcnt[64], bbase[64];
     if (lane == 63) wtot[wave] = incl;
-    if (band_count && threadIdx.x < 64) bcnt[threadIdx.x] = 0;
     __syncthreads();
     uint32_t base = block_offsets[blockIdx.x];
     for (int w = 0; w < wave; w++) base += wtot[w];
+    if (idx >= P) return;
     const uint32_t end = base + incl;
     uint32_t off = end - n;
-    uint32_t mnx = 0, mny = 0, mxx = 0, mxy = 0, dbits = 0;
-    if (idx < P) point_offsets[idx] = end;
-    if (n != 0) {
-        float* rec = splat + (size_t)idx * GSR_SPLAT_F;
-        const float mx = rec[SP_MX], my = rec[SP_MY];
-        dbits = __float_as_uint(rec[SP_DEPTH]);
-        const int radius = __float_as_int(rec[SP_RADIUS]);
-        rec[SP_OFFS] = __uint_as_float(off);
-        gsr_get_rect(mx, my, radius, gx, gy, mnx, mny, mxx, mxy);
-    }
-    if (band_count) {  // workgroup-uniform
-        int b0 = 0, b1 = -1;
-        if (n != 0) { b0 = (int)mny / bh; b1 = (int)(mxy - 1) / bh; }
-        for (int b = b0; b <= b1; b++) atomicAdd(&bcnt[b], 1u);
-        __syncthreads();
-        if ((int)threadIdx.x < nb) {
-            const uint32_t c = bcnt[threadIdx.x];
-            bbase[threadIdx.x] = c ? atomicAdd(&band_count[threadIdx.x], c) : 0u;
-            bcnt[threadIdx.x] = 0;
-        }
-        __syncthreads();
-        for (int b = b0; b <= b1; b++) band_list[(size_t)b * P + bbase[b] + atomicAdd(&bcnt[b], 1u)] = (uint32_t)idx;
-    }
-    if (n == 0 || keys == nullptr) return;  // offsets only: the tile-binning path (binning.hip) builds the lists itself
+    point_offsets[idx] = end;
+    if (n == 0) return;
+    float* rec = splat + (size_t)idx * GSR_SPLAT_F;
+    const float mx = rec[SP_MX], my = rec[SP_MY];
+    const uint32_t dbits = __float_as_uint(rec[SP_DEPTH]);
+    const int radius = __float_as_int(rec[SP_RADIUS]);
+    rec[SP_OFFS] = __uint_as_float(off);
+    if (keys == nullptr) return;  // offsets only: the tile-binning path (binning.hip) builds the lists itself
+    uint32_t mnx, mny, mxx, mxy;
+    gsr_get_rect(mx, my, radius, gx, gy, mnx, mny, mxx, mxy);
     for (uint32_t y = mny; y < mxy; y++)
         for (uint32_t x = mnx; x < mxx; x++) {
             keys[off] = ((uint64_t)(y * (uint32_t)gx + x) << 32) | dbits;
@@ -366,14 +350,9 @@ void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_to
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     int nb = 0, bh = 1;
-    uint32_t *band_count = nullptr, *band_list = nullptr;
-    if (band_mem && gsr_band_geometry(gx, gy, &nb, &bh)) {  // banded tile binning: partition the Gaussians into bands on the way
-        band_count = band_mem;
-        band_list = band_mem + GSR_BAND_COUNTERS;
-        hipMemsetAsync(band_count, 0, GSR_BAND_COUNTERS * 4, s);
-    }
+    uint32_t* band_count = (band_mem && gsr_band_geometry(gx, gy, &nb, &bh)) ? band_mem : nullptr;
     hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, splat, tiles_touched, block_offsets,
-                       point_offsets, keys, vals, nb, bh, band_count, band_list);
+                       point_offsets, keys, vals, band_count);
 }
 
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s)
