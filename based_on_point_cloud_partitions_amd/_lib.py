@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -59,6 +59,7 @@ PROTOTYPES = {
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),
     "gsr_profile_enable": (None, [c_int]),
+    "gsr_profile_select": (None, [ctypes.c_uint32]),
     "gsr_profile_collect": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64), c_int]),
     "gsr_sort_scratch_bytes": (c_size, [c_i64]),
     "gsr_sort_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_size, c_void_p]),
@@ -101,8 +102,12 @@ STAGES = ["preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges", "rende
           "gaussian_backward"]
 
 
-def profile_enable(on):
-    load().gsr_profile_enable(1 if on else 0)
+def profile_enable(on, stages=None):
+    """Per-stage HIP-event timing on/off; `stages` = iterable of stage names to restrict it to (None = all)."""
+    lib = load()
+    mask = 0xFFFFFFFF if stages is None else sum(1 << STAGES.index(n) for n in stages)
+    lib.gsr_profile_select(mask)
+    lib.gsr_profile_enable(1 if on else 0)
 
 
 def profile_collect():

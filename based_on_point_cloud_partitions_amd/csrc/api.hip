@@ -31,14 +31,16 @@ int check_hip(const char* what)
 }
 
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline figures) ----
-struct ProfRec { int stage; hipEvent_t a, b; };
+struct ProfRec { int stage; hipEvent_t a, b; bool count; };
 bool g_prof = false;
+uint32_t g_prof_mask = 0xFFFFFFFFu;  // stages that get events while g_prof is set
 std::vector<ProfRec> g_recs;
 std::mutex g_prof_mu;
 
 struct StageTimer {
-    int stage; hipStream_t s; hipEvent_t a, b; bool on;
-    StageTimer(int stage_, hipStream_t s_) : stage(stage_), s(s_), on(g_prof)
+    int stage; hipStream_t s; hipEvent_t a, b; bool on, count;  // count = false: a second segment of a stage already counted
+    StageTimer(int stage_, hipStream_t s_, bool count_ = true)
+        : stage(stage_), s(s_), on(g_prof && ((g_prof_mask >> stage_) & 1u)), count(count_)
     {
         if (on) {
             hipEventCreate(&a);
@@ -51,7 +53,7 @@ struct StageTimer {
         if (on) {
             hipEventRecord(b, s);
             std::lock_guard<std::mutex> lk(g_prof_mu);
-            g_recs.push_back({stage, a, b});
+            g_recs.push_back({stage, a, b, count});
         }
     }
 };
@@ -148,9 +150,11 @@ size_t gsr_image_bytes(int W, int H) { return gsr_image_layout(W, H).bytes; }
 size_t gsr_binning_bytes(int64_t R, int P, int W, int H) { return gsr_bin_layout((long)R, P, W, H).bytes; }
 size_t gsr_backward_scratch_bytes(int64_t R) { return gsr_align((size_t)(R > 0 ? R : 1) * GSR_GROW_F * 4); }
 
-// Phase 1 shared by gsr_forward_geometry and gsr_forward_params: `a` carries the inputs, the outputs inside the geometry
-// buffer are filled in here.
-static int run_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_bytes, int64_t* num_rendered_host, hipStream_t s)
+// Phase 1 shared by gsr_forward_geometry, gsr_forward and gsr_forward_params: `a` carries the inputs, the outputs inside the
+// geometry buffer are filled in here.  launch_geometry enqueues the two kernels, wait_geometry returns R.
+struct GeometryWait { bool mail = false; unsigned long long* mail_host = nullptr; uint32_t seq = 0; char* total_dev = nullptr; };
+
+static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_bytes, GeometryWait* w, hipStream_t s)
 {
     const int P = a.P;
     const GeomLayout L = gsr_geom_layout(P);
@@ -160,21 +164,61 @@ static int run_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_bytes, 
     a.tiles_touched = (uint32_t*)(g + L.tiles_touched); a.block_sums = (uint32_t*)(g + L.block_sums);
     { StageTimer t(GSR_STAGE_PREPROCESS, s); gsr_launch_preprocess(a, s); }
     const int nb = (P + 255) / 256;
-    unsigned long long *mail_host = nullptr, *mail_dev = nullptr;
-    uint32_t seq = 0;
-    const bool mail = gsr_variant("MAILBOX", 1) && mailbox_acquire(&mail_host, &mail_dev, &seq);
+    unsigned long long* mail_dev = nullptr;
+    w->mail = gsr_variant("MAILBOX", 1) && mailbox_acquire(&w->mail_host, &mail_dev, &w->seq);
+    w->total_dev = g + L.total;
     {
         StageTimer t(GSR_STAGE_SCAN, s);
-        gsr_launch_scan_blocks(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), mail ? mail_dev : nullptr, seq, s);
+        gsr_launch_scan_blocks(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), w->mail ? mail_dev : nullptr,
+                               w->seq, s);
     }
+    return 0;
+}
+
+static int wait_geometry(const GeometryWait& w, int64_t* num_rendered_host, hipStream_t s)
+{
     uint32_t total = 0;
-    if (!mail || !mailbox_wait(mail_host, seq, &total)) {
-        hipError_t e = hipMemcpyAsync(&total, g + L.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (!w.mail || !mailbox_wait(w.mail_host, w.seq, &total)) {
+        hipError_t e = hipMemcpyAsync(&total, w.total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(-100, "forward_geometry: %s", hipGetErrorString(e));
     }
     *num_rendered_host = (int64_t)total;
     return check_hip("forward_geometry");
+}
+
+static int run_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_bytes, int64_t* num_rendered_host, hipStream_t s)
+{
+    GeometryWait w;
+    const int rc = launch_geometry(a, geom_buffer, geom_bytes, &w, s);
+    return rc != 0 ? rc : wait_geometry(w, num_rendered_host, s);
+}
+
+// argument checks of RasterizeGaussiansCUDA (rasterize_points.cu:57-113) + the launch descriptor; 1 = nothing to do (P == 0)
+static int make_std_args(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier, const float* rotations,
+                         const float* opacities, const float* shs, const float* cov3D_precomp, const float* colors_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H, float tan_fovx,
+                         float tan_fovy, int* radii, void* geom_buffer, int64_t* num_rendered_host, PreprocessArgs* out)
+{
+    if (!num_rendered_host) return fail(-1, "num_rendered_host is NULL");
+    *num_rendered_host = 0;
+    if (P < 0 || W <= 0 || H <= 0) return fail(-1, "invalid sizes");
+    if (P == 0) return 1;
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer)
+        return fail(-1, "NULL required pointer");
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(-2, "provide exactly one of shs / colors_precomp");
+    if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
+        return fail(-2, "provide scales+rotations or cov3D_precomp");
+    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(-2, "SH degree / coefficient count mismatch");
+    PreprocessArgs& a = *out;
+    a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
+    a.means3D = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.shs = shs;
+    a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
+    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.radii = radii;
+    a.raw = 0; a.features_dc = nullptr; a.features_rest = nullptr;
+    return 0;
 }
 
 int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
@@ -184,33 +228,41 @@ int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float*
                          size_t geom_bytes, int64_t* num_rendered_host, void* stream)
 {
     (void)prefiltered;  // only selects a device-side trap in the reference (auxiliary.h:156-160)
-    hipStream_t s = (hipStream_t)stream;
-    if (!num_rendered_host) return fail(-1, "num_rendered_host is NULL");
-    *num_rendered_host = 0;
-    if (P < 0 || W <= 0 || H <= 0) return fail(-1, "invalid sizes");
-    if (P == 0) return 0;
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer)
-        return fail(-1, "NULL required pointer");
-    if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(-2, "provide exactly one of shs / colors_precomp");
-    if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
-        return fail(-2, "provide scales+rotations or cov3D_precomp");
-    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(-2, "SH degree / coefficient count mismatch");
     PreprocessArgs a;
-    a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
-    a.means3D = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.shs = shs;
-    a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
-    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
-    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
-    a.radii = radii;
-    a.raw = 0; a.features_dc = nullptr; a.features_rest = nullptr;
-    return run_geometry(a, geom_buffer, geom_bytes, num_rendered_host, s);
+    const int rc = make_std_args(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                                 viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, geom_buffer, num_rendered_host, &a);
+    if (rc != 0) return rc < 0 ? rc : 0;
+    return run_geometry(a, geom_buffer, geom_bytes, num_rendered_host, (hipStream_t)stream);
 }
 
-int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, void* geom_buffer, size_t geom_bytes,
-                       void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes,
-                       float* out_color, void* stream)
+// The stages of phase 2 that need neither R nor the R-sized arrays: instance offsets (emit) and the head of the tile binning.
+// gsr_forward / gsr_forward_params enqueue them BEFORE waiting for R, so the host round trip overlaps with GPU work.
+static void launch_render_head(int P, int W, int H, void* geom_buffer, void* binning_buffer, hipStream_t s)
 {
-    hipStream_t s = (hipStream_t)stream;
+    const GeomLayout G = gsr_geom_layout(P);
+    const BinLayout B = gsr_bin_layout(0, P, W, H);  // the offsets used here do not depend on R
+    char* g = (char*)geom_buffer;
+    char* b = (char*)binning_buffer;
+    {   // per-Gaussian instance offsets only (needed by the backward's gradient-row addressing)
+        StageTimer t(GSR_STAGE_EMIT, s);
+        gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched), (const uint32_t*)(g + G.block_offsets),
+                        (uint32_t*)(g + G.point_offsets), nullptr, nullptr, (uint32_t*)(b + B.band), s);
+    }
+    StageTimer t(GSR_STAGE_SORT, s);
+    gsr_launch_tile_binning_head(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
+                                 (uint32_t*)(b + B.band), s);
+}
+
+static bool can_launch_head_early(int P, int W, int H, const void* binning_buffer, size_t binning_bytes)
+{
+    return P > 0 && gsr_variant("BIN", 1) && gsr_variant("EARLY", 1) && binning_buffer &&
+           binning_bytes >= gsr_bin_layout(0, P, W, H).fixed_bytes;
+}
+
+static int forward_render_impl(int P, int64_t R, int W, int H, const float* background, void* geom_buffer, size_t geom_bytes,
+                               void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes, float* out_color,
+                               bool head_done, hipStream_t s)
+{
     if (P == 0) return 0;
     if (!background || !geom_buffer || !image_buffer || !out_color) return fail(-1, "NULL required pointer");
     if (R < 0 || R > 0xFFFFFFFFll) return fail(-1, "num_rendered out of range");
@@ -232,16 +284,11 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
         uint32_t* va = (uint32_t*)(b + B.vals_a);
         uint32_t* vb = (uint32_t*)(b + B.vals_b);
         if (gsr_variant("BIN", 1)) {
-            {   // per-Gaussian instance offsets only (needed by the backward's gradient-row addressing)
-                StageTimer t(GSR_STAGE_EMIT, s);
-                gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
-                                (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets), nullptr, nullptr,
-                                (uint32_t*)(b + B.band), s);
-            }
-            StageTimer t(GSR_STAGE_SORT, s);
-            gsr_launch_tile_binning(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
-                                    (uint32_t*)(b + B.order), ranges, (uint32_t*)(b + B.band), ka, va,
-                                    gsr_variant("KEYS", 0) ? kb : nullptr, s);
+            if (!head_done) launch_render_head(P, W, H, geom_buffer, binning_buffer, s);
+            StageTimer t(GSR_STAGE_SORT, s, false);
+            gsr_launch_tile_binning_tail(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
+                                         (uint32_t*)(b + B.order), ranges, (uint32_t*)(b + B.band), ka, va,
+                                         gsr_variant("KEYS", 0) ? kb : nullptr, s);
             point_list = va;
         } else {
         {
@@ -261,6 +308,7 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
         }
     } else {
         // point_offsets must still be valid for the backward pass; no instances -> all ranges empty
+        // (an early head, if any, wrote the same zeros)
         hipMemsetAsync(g + G.point_offsets, 0, (size_t)P * 4, s);
         gsr_launch_tile_ranges(0, nullptr, ranges, (uint32_t)(gx * gy), s);
     }
@@ -273,6 +321,32 @@ int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, 
     return check_hip("forward_render");
 }
 
+int gsr_forward_render(int P, int64_t R, int W, int H, const float* background, void* geom_buffer, size_t geom_bytes,
+                       void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes,
+                       float* out_color, void* stream)
+{
+    return forward_render_impl(P, R, W, H, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer,
+                               image_bytes, out_color, false, (hipStream_t)stream);
+}
+
+// phases 1 + 2 with the R round trip hidden behind the R-independent head of phase 2
+static int forward_fused(const PreprocessArgs& a, const float* background, void* geom_buffer, size_t geom_bytes, void* binning_buffer,
+                         size_t binning_bytes, void* image_buffer, size_t image_bytes, float* out_color, int64_t* num_rendered_host,
+                         hipStream_t s)
+{
+    GeometryWait w;
+    int rc = launch_geometry(a, geom_buffer, geom_bytes, &w, s);
+    if (rc != 0) return rc;
+    const bool early = can_launch_head_early(a.P, a.W, a.H, binning_buffer, binning_bytes);
+    if (early) launch_render_head(a.P, a.W, a.H, geom_buffer, binning_buffer, s);
+    rc = wait_geometry(w, num_rendered_host, s);
+    if (rc != 0) return rc;
+    const int64_t R = *num_rendered_host;
+    if (R > 0 && gsr_bin_layout((long)R, a.P, a.W, a.H).bytes > binning_bytes) return 1;  // caller re-allocates, then gsr_forward_render
+    return forward_render_impl(a.P, R, a.W, a.H, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer,
+                               image_bytes, out_color, early, s);
+}
+
 int gsr_forward(int P, int D, int M, const float* background, const float* means3D, const float* scales, float scale_modifier,
                 const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
                 const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H,
@@ -280,14 +354,13 @@ int gsr_forward(int P, int D, int M, const float* background, const float* means
                 void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes, float* out_color,
                 int64_t* num_rendered_host, void* stream)
 {
-    const int rc = gsr_forward_geometry(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
-                                        colors_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered, radii,
-                                        geom_buffer, geom_bytes, num_rendered_host, stream);
-    if (rc != 0) return rc;
-    const int64_t R = *num_rendered_host;
-    if (R > 0 && gsr_bin_layout((long)R, P, W, H).bytes > binning_bytes) return 1;  // caller re-allocates and calls gsr_forward_render
-    return gsr_forward_render(P, R, W, H, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer,
-                              image_bytes, out_color, stream);
+    (void)prefiltered;
+    PreprocessArgs a;
+    const int rc = make_std_args(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                                 viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, geom_buffer, num_rendered_host, &a);
+    if (rc != 0) return rc < 0 ? rc : 0;
+    return forward_fused(a, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer, image_bytes, out_color,
+                         num_rendered_host, (hipStream_t)stream);
 }
 
 int gsr_forward_params(int P, int D, int M, const float* background, const float* xyz, const float* features_dc,
@@ -315,12 +388,8 @@ int gsr_forward_params(int P, int D, int M, const float* background, const float
     a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
     a.radii = radii;
     a.raw = 1; a.features_dc = features_dc; a.features_rest = features_rest;
-    const int rc = run_geometry(a, geom_buffer, geom_bytes, num_rendered_host, s);
-    if (rc != 0) return rc;
-    const int64_t R = *num_rendered_host;
-    if (R > 0 && gsr_bin_layout((long)R, P, W, H).bytes > binning_bytes) return 1;  // caller re-allocates and calls gsr_forward_render
-    return gsr_forward_render(P, R, W, H, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer,
-                              image_bytes, out_color, stream);
+    return forward_fused(a, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer, image_bytes, out_color,
+                         num_rendered_host, s);
 }
 
 // Shared by gsr_backward and gsr_backward_params: `a` carries the per-Gaussian inputs and the output pointers.
@@ -587,6 +656,12 @@ void gsr_profile_enable(int on)
     g_prof = on != 0;
 }
 
+void gsr_profile_select(uint32_t stage_mask)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_mask = stage_mask;
+}
+
 int gsr_profile_collect(double* ms_per_stage, int64_t* launches_per_stage, int nstages)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -595,7 +670,7 @@ int gsr_profile_collect(double* ms_per_stage, int64_t* launches_per_stage, int n
     for (const ProfRec& r : g_recs) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = -100;
-        else if (r.stage < nstages) { ms_per_stage[r.stage] += ms; launches_per_stage[r.stage] += 1; }
+        else if (r.stage < nstages) { ms_per_stage[r.stage] += ms; launches_per_stage[r.stage] += r.count ? 1 : 0; }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
     }

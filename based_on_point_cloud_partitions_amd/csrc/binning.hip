@@ -658,9 +658,8 @@ size_t gsr_band_list_bytes(int P, int W, int H)
     return (size_t)G.nb * (size_t)(P > 0 ? P : 1) * 4 + GSR_BAND_COUNTERS * 4;  // id lists + the band counters in front
 }
 
-void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
-                             uint32_t* ranges, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
-                             hipStream_t s)
+void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* band_mem,
+                                  hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int T = gx * gy;
@@ -672,18 +671,35 @@ void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* 
         uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
         hipLaunchKernelGGL(band_partition_kernel, dim3((P + SLICE_THREADS - 1) / SLICE_THREADS), dim3(SLICE_THREADS), 0, s, P, G, splat,
                            band_count, band_list);
-        const size_t lds = (size_t)G.tmax * 4;
-        const int nwg = G.nb * BAND_SLICES;
-        hipLaunchKernelGGL(tile_count_banded_kernel, dim3(nwg), dim3(SLICE_THREADS), lds, s, P, G, splat, band_count, band_list, table);
+        hipLaunchKernelGGL(tile_count_banded_kernel, dim3(G.nb * BAND_SLICES), dim3(SLICE_THREADS), (size_t)G.tmax * 4, s, P, G, splat,
+                           band_count, band_list, table);
         hipLaunchKernelGGL(tile_colscan_banded_kernel, dim3((G.tmax + 31) / 32, G.nb), dim3(256), 0, s, G, table, totals);
-        hipLaunchKernelGGL(tile_scatter_banded_kernel, dim3(nwg + 1), dim3(SLICE_THREADS), lds, s, P, G, splat, band_count, band_list, table,
-                           totals, ranges, order, reinterpret_cast<uint2*>(bins));
     } else {
         int gpb;
         const int ns = gsr_tile_slices(P, &gpb);
         const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
         hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table);
         hipLaunchKernelGGL(tile_colscan_kernel, dim3((T + 31) / 32), dim3(256), 0, s, T, ns, table, totals);
+    }
+}
+
+void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
+                                  uint32_t* ranges, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
+                                  hipStream_t s)
+{
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    const int T = gx * gy;
+    const BandGeom G = band_geom(gx, gy);
+    int nb_, bh_;
+    if (band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_)) {
+        const uint32_t* band_count = band_mem;
+        const uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
+        hipLaunchKernelGGL(tile_scatter_banded_kernel, dim3(G.nb * BAND_SLICES + 1), dim3(SLICE_THREADS), (size_t)G.tmax * 4, s, P, G, splat,
+                           band_count, band_list, table, totals, ranges, order, reinterpret_cast<uint2*>(bins));
+    } else {
+        int gpb;
+        const int ns = gsr_tile_slices(P, &gpb);
+        const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
         hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table, totals, ranges,
                            order, reinterpret_cast<uint2*>(bins));
     }

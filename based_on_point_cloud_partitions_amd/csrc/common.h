@@ -29,7 +29,7 @@ struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
 };
 struct BinLayout {
-    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, band, bytes;
+    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, band, fixed_bytes, bytes;
     uint32_t sort_blocks;
 };
 
@@ -74,18 +74,14 @@ int gsr_tile_slices(int P, int* gpb_out);
 size_t gsr_band_table_bytes(int W, int H);
 size_t gsr_band_list_bytes(int P, int W, int H);
 
+// The part of the binning buffer whose size does not depend on R comes first: the stages that only need it (instance
+// offsets, band partition, tile histograms) can be enqueued before the host knows R (gsr_forward).
 static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
 {
     BinLayout L;
     size_t o = 0, r = (size_t)(R > 0 ? R : 1);
     L.sort_blocks = (uint32_t)((r + GSR_SORT_TILE - 1) / GSR_SORT_TILE);
-    L.keys_a = o; o = gsr_align(o + r * 8);
-    L.keys_b = o; o = gsr_align(o + r * 8);
-    L.vals_a = o; o = gsr_align(o + r * 4);
-    L.vals_b = o; o = gsr_align(o + r * 4);
-    L.hist_global = o; o = gsr_align(o + 8 * 256 * 4);
-    L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
-    {   // tile binning (binning.hip): [slice][tile] counters, tile totals, tile starts
+    {   // tile binning (binning.hip): [slice][tile] counters, tile totals, launch order, band lists
         int gpb;
         const size_t ns = (size_t)gsr_tile_slices(P, &gpb);
         size_t t = (size_t)((W + GSR_TILE_X - 1) / GSR_TILE_X) * ((H + GSR_TILE_Y - 1) / GSR_TILE_Y);
@@ -97,6 +93,13 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
         L.order = o; o = gsr_align(o + t * 4);  // tiles by descending list length: launch order of the blend kernels
         L.band = o; o = gsr_align(o + gsr_band_list_bytes(P, W, H));  // band counters + per-band Gaussian id lists
     }
+    L.hist_global = o; o = gsr_align(o + 8 * 256 * 4);
+    L.fixed_bytes = o;  // everything above is independent of R
+    L.keys_a = o; o = gsr_align(o + r * 8);
+    L.keys_b = o; o = gsr_align(o + r * 8);
+    L.vals_a = o; o = gsr_align(o + r * 4);
+    L.vals_b = o; o = gsr_align(o + r * 4);
+    L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
     L.bytes = o;
     return L;
 }
@@ -139,9 +142,13 @@ bool gsr_band_geometry(int gx, int gy, int* nb, int* bh);
 int gsr_launch_radix_sort(uint64_t* ka, uint64_t* kb, uint32_t* va, uint32_t* vb, uint32_t n, int end_bit,
                           uint32_t* hist_global, uint32_t* hist_blocks, uint32_t nblocks, hipStream_t s);
 static inline int gsr_sort_result_in_b(int end_bit) { return (((end_bit + 7) / 8) & 1); }
-void gsr_launch_tile_binning(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
-                             uint32_t* ranges, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
-                             hipStream_t s);
+// head: everything that does not need the R-sized arrays (band partition, tile histograms, column scan -> totals);
+// tail: scatter into the tile segments + per-tile sorts
+void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* band_mem,
+                                  hipStream_t s);
+void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
+                                  uint32_t* ranges, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
+                                  hipStream_t s);
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,

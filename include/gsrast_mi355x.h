@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -180,6 +180,9 @@ enum {
     GSR_STAGE_RENDER_FWD = 5, GSR_STAGE_RENDER_BWD = 6, GSR_STAGE_GAUSS_BWD = 7, GSR_NUM_STAGES = 8
 };
 void gsr_profile_enable(int on);
+/* Restricts the events to the stages whose bit is set (bit i = stage i; default all).  Every pair of events costs a few
+ * microseconds of stream time, so a timed run that only needs the dominant stage selects that one. */
+void gsr_profile_select(uint32_t stage_mask);
 int gsr_profile_collect(double* ms_per_stage, int64_t* launches_per_stage, int nstages);
 
 #ifdef __cplusplus
