@@ -410,12 +410,13 @@ void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* po
                         /* out */ float* final_T, uint32_t* n_contrib, float* out_color, long long* stats)
 {
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
-    long long visited = 0, blended = 0, strips = 0, touched = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : visited, blended, strips, touched)
+    long long visited = 0, blended = 0, strips = 0, touched = 0, heavy8 = 0, qmax = 0, qsum = 0, hmax = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : visited, blended, strips, touched, heavy8, qmax, qsum, hmax)
     for (int tile = 0; tile < gx * gy; tile++) {
         int ty = tile / gx, tx = tile % gx;
         uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
         uint8_t* sflag = stats ? (uint8_t*)calloc((size_t)(r1 - r0) + 1, 1) : NULL;
+        uint16_t* qflag = stats ? (uint16_t*)calloc((size_t)(r1 - r0) + 1, 2) : NULL; /* 4x4-pixel quarters that blend the entry */
         for (int ly = 0; ly < BLOCK_Y; ly++)
             for (int lx = 0; lx < BLOCK_X; lx++) {
                 int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
@@ -437,7 +438,7 @@ void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* po
                     T = test_T;
                     last_contributor = contributor;
                     blended++;
-                    if (sflag) sflag[k - r0] |= (uint8_t)(1u << (ly / 4));
+                    if (sflag) { sflag[k - r0] |= (uint8_t)(1u << (ly / 4)); qflag[k - r0] |= (uint16_t)(1u << ((ly / 4) * 4 + lx / 4)); }
                 }
                 size_t pix_id = (size_t)W * py + px;
                 final_T[pix_id] = T;
@@ -448,9 +449,32 @@ void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* po
         if (sflag) {
             for (uint32_t k = 0; k < r1 - r0; k++) { strips += __builtin_popcount(sflag[k]); if (sflag[k]) touched++; }
             free(sflag);
+            /* what-if statistics for sub-wave work lists: a wave owns an 8x8 block = 4 quarters of 4x4 pixels */
+            for (int wv = 0; wv < 4; wv++) {
+                const int wy = wv / 2, wx = wv % 2;
+                int qb[4];
+                for (int j = 0; j < 4; j++) qb[j] = (2 * wy + j / 2) * 4 + 2 * wx + j % 2;
+                long long len[4] = {0, 0, 0, 0}, lenh[2] = {0, 0}, hv = 0;
+                for (uint32_t k = 0; k < r1 - r0; k++) {
+                    int any = 0, h0 = 0, h1 = 0;
+                    for (int j = 0; j < 4; j++)
+                        if (qflag[k] >> qb[j] & 1) { len[j]++; any = 1; if (j < 2) h0 = 1; else h1 = 1; }
+                    hv += any; lenh[0] += h0; lenh[1] += h1;
+                }
+                heavy8 += hv;
+                long long m = len[0];
+                for (int j = 1; j < 4; j++) if (len[j] > m) m = len[j];
+                qmax += m;
+                qsum += len[0] + len[1] + len[2] + len[3];
+                hmax += lenh[0] > lenh[1] ? lenh[0] : lenh[1];
+            }
+            free(qflag);
         }
     }
-    if (stats) { stats[0] = visited; stats[1] = blended; stats[2] = strips; stats[3] = touched; }
+    if (stats) {
+        stats[0] = visited; stats[1] = blended; stats[2] = strips; stats[3] = touched;
+        stats[4] = heavy8; stats[5] = qmax; stats[6] = qsum; stats[7] = hmax;
+    }
 }
 
 /* K8 renderCUDA backward, backward.cu:399-557.  The reference accumulates the 9

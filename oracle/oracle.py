@@ -111,7 +111,7 @@ def forward(means3D, opacities, *, shs=None, colors_precomp=None, scales=None, r
     st["values_unsorted"] = np.zeros(n, np.uint32)[:R]
     st["keys_sorted"] = np.zeros(n, np.uint64)[:R]
     st["point_list"] = np.zeros(n, np.uint32)[:R]
-    st["stats"] = np.zeros(4, np.int64)
+    st["stats"] = np.zeros(8, np.int64)  # visited, blended, 16x4 strips, touched entries, 8x8 heavy, sum max quarter, sum quarters, sum max half
     if P > 0:
         L.orc_binning(ctypes.c_int(P), ctypes.c_long(R), ctypes.c_int(W), ctypes.c_int(H), _p(st["radii"], _i),
                       _p(st["means2D"], _f), _p(st["depths"], _f), _p(st["point_offsets"], _u32),
