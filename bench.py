@@ -393,6 +393,9 @@ def main():
                     roofline["traffic"] = json.load(open(pmc)).get(d["kernel"], {}).get("hbm_bytes")
                 except Exception:
                     pass
+            for extra in ("valu_insts", "simd_cycles_per_valu_inst"):  # what actually bounds the blend kernels
+                if extra in d:
+                    roofline[extra] = d[extra]
         fwd_ms = sum(k["avg_ms"] for k in kernels if k["kernel"] in
                      ("preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges", "render_forward"))
         out = {
