@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -55,6 +55,11 @@ PROTOTYPES = {
     "gsr_loss_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p]),
     "gsr_loss_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
+    "gsr_appearance_saved_bytes": (c_size, [c_int, c_int]),
+    "gsr_appearance_scratch_bytes": (c_size, [c_int, c_int]),
+    "gsr_appearance_tail_forward": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p, c_size, c_void_p]),
+    "gsr_appearance_tail_backward": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p, c_size] + [c_void_p] * 8 +
+                                     [c_void_p, c_size, c_void_p]),
     "gsr_knn_scratch_bytes": (c_size, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),

@@ -527,6 +527,46 @@ int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2,
     return check_hip("loss_backward");
 }
 
+size_t gsr_appearance_saved_bytes(int H, int W) { return H > 0 && W > 0 ? (size_t)16 * H * W * sizeof(float) : 0; }
+
+size_t gsr_appearance_scratch_bytes(int H, int W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    size_t a, b, c, d;
+    return gsr_appearance_layout(H, W, &a, &b, &c, &d);
+}
+
+int gsr_appearance_tail_forward(int H, int W, int feat_h, int feat_w, const float* feat, const float* conv2_weight,
+                                const float* conv2_bias, const float* conv3_weight, const float* conv3_bias, const float* image,
+                                float* mapping, float* transformed, void* saved, size_t saved_bytes, void* stream)
+{
+    if (H <= 0 || W <= 0 || feat_h <= 0 || feat_w <= 0) return fail(-1, "invalid image / feature size");
+    if (!feat || !conv2_weight || !conv2_bias || !conv3_weight || !conv3_bias || !image || !mapping || !transformed || !saved)
+        return fail(-1, "NULL required pointer");
+    if (saved_bytes < gsr_appearance_saved_bytes(H, W)) return fail(-3, "appearance saved buffer too small");
+    gsr_launch_appearance_forward(H, W, feat_h, feat_w, feat, conv2_weight, conv2_bias, conv3_weight, conv3_bias, image, mapping,
+                                  transformed, (float*)saved, (hipStream_t)stream);
+    return check_hip("appearance_tail_forward");
+}
+
+int gsr_appearance_tail_backward(int H, int W, int feat_h, int feat_w, const float* feat, const float* conv2_weight,
+                                 const float* conv3_weight, const float* image, const float* mapping, const void* saved,
+                                 size_t saved_bytes, const float* dL_dtransformed, const float* dL_dmapping, float* dL_dimage,
+                                 float* dL_dfeat, float* dL_dconv2_weight, float* dL_dconv2_bias, float* dL_dconv3_weight,
+                                 float* dL_dconv3_bias, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (H <= 0 || W <= 0 || feat_h <= 0 || feat_w <= 0) return fail(-1, "invalid image / feature size");
+    if (!feat || !conv2_weight || !conv3_weight || !image || !mapping || !saved || !dL_dtransformed || !dL_dimage || !dL_dfeat ||
+        !dL_dconv2_weight || !dL_dconv2_bias || !dL_dconv3_weight || !dL_dconv3_bias || !scratch)
+        return fail(-1, "NULL required pointer");
+    if (saved_bytes < gsr_appearance_saved_bytes(H, W)) return fail(-3, "appearance saved buffer too small");
+    if (scratch_bytes < gsr_appearance_scratch_bytes(H, W)) return fail(-3, "appearance scratch too small");
+    gsr_launch_appearance_backward(H, W, feat_h, feat_w, feat, conv2_weight, conv3_weight, image, mapping, (const float*)saved,
+                                   dL_dtransformed, dL_dmapping, dL_dimage, dL_dfeat, dL_dconv2_weight, dL_dconv2_bias,
+                                   dL_dconv3_weight, dL_dconv3_bias, (char*)scratch, (hipStream_t)stream);
+    return check_hip("appearance_tail_backward");
+}
+
 int gsr_adam_step(int n_tensors, const gsr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream)
 {
     static_assert(sizeof(gsr_adam_tensor) == sizeof(GsrAdamTensorHost), "ABI struct mismatch");

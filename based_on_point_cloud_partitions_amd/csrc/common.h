@@ -174,6 +174,13 @@ struct GaussBackwardArgs {
 void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s);
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
+size_t gsr_appearance_layout(int H, int W, size_t* dz2_off, size_t* du_off, size_t* p3_off, size_t* p2_off);
+void gsr_launch_appearance_forward(int H, int W, int Hh, int Wh, const float* feat, const float* w2, const float* b2, const float* w3,
+                                   const float* b3, const float* image, float* mapping, float* transformed, float* saved_a, hipStream_t s);
+void gsr_launch_appearance_backward(int H, int W, int Hh, int Wh, const float* feat, const float* w2, const float* w3, const float* image,
+                                    const float* mapping, const float* saved_a, const float* g_transformed, const float* g_mapping,
+                                    float* dimage, float* dfeat, float* dw2, float* db2, float* dw3, float* db3, char* scratch,
+                                    hipStream_t s);
 size_t gsr_loss_scratch_layout(int C, int H, int W, size_t* maps_off, size_t* partials_off);
 void gsr_launch_loss_forward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda,
                              float* maps, float* partials, float* out3, hipStream_t s);

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6
+#define GSR_ABI_VERSION 7
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -128,6 +128,26 @@ int gsr_loss_forward(int C, int H, int W, const float* img1, const float* img2, 
 int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda_dssim,
                       const void* scratch, size_t scratch_bytes, const float* grad_loss, float* dL_dimg1, float* dL_dimg_l1,
                       void* stream);
+
+/* Appearance decoupling of the reference's training loop (train.py:110-111): the full-resolution tail of
+ * AppearanceNetwork.forward (scene/ptgs/appearance_network.py:54-60) and `transformed_image = mapping_image * image` (:15):
+ *   u = bilinear(feat -> H x W, align_corners=True); a = relu(conv2(u)); mapping = sigmoid(conv3(a)); transformed = mapping * image
+ * feat = output of `up4` [16][feat_h][feat_w]; conv2 is Conv2d(16, 16, 3, padding=1) (weight [16][16][3][3], bias [16]), conv3
+ * Conv2d(16, 3, 3, padding=1) (weight [3][16][3][3], bias [3]); image, mapping, transformed are [3][H][W].  Everything is
+ * float32 on the device.  The forward keeps `a` in `saved` (gsr_appearance_saved_bytes) for the backward, which returns the
+ * gradients of feat, the four parameter tensors and the image -- for the image the direct `mapping * dL_dtransformed` term;
+ * the path through the network's down-sampled input is upstream of feat and stays with the caller's autograd.
+ * dL_dmapping may be NULL (train.py uses only the transformed image). */
+size_t gsr_appearance_saved_bytes(int H, int W);
+size_t gsr_appearance_scratch_bytes(int H, int W);
+int gsr_appearance_tail_forward(int H, int W, int feat_h, int feat_w, const float* feat, const float* conv2_weight,
+                                const float* conv2_bias, const float* conv3_weight, const float* conv3_bias, const float* image,
+                                float* mapping, float* transformed, void* saved, size_t saved_bytes, void* stream);
+int gsr_appearance_tail_backward(int H, int W, int feat_h, int feat_w, const float* feat, const float* conv2_weight,
+                                 const float* conv3_weight, const float* image, const float* mapping, const void* saved,
+                                 size_t saved_bytes, const float* dL_dtransformed, const float* dL_dmapping, float* dL_dimage,
+                                 float* dL_dfeat, float* dL_dconv2_weight, float* dL_dconv2_bias, float* dL_dconv3_weight,
+                                 float* dL_dconv3_bias, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Optimizer step of the training loop: torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of
  * scene/gaussian_model.py:164-175 / train.py:155-157 for ALL parameter tensors in one launch -- dense Adam, weight_decay = 0,

@@ -253,3 +253,91 @@ def l1_ssim_loss(img1, img2, lambda_dssim=0.2, grad=True):
     L.orc_l1_ssim_loss(ctypes.c_int(C), ctypes.c_int(H), ctypes.c_int(W), _p(a, _f), _p(b, _f), ctypes.c_float(lambda_dssim),
                        _p(out, _f), _p(g, _f))
     return float(out[0]), float(out[1]), float(out[2]), g
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Appearance-decoupling network, full-resolution tail: scene/ptgs/appearance_network.py:52-60 from the
+# bilinear upsampling on, and `transformed_image = mapping_image * image` (:15).  numpy fp32; pinned by
+# tests/golden/ref_appearance.npz, which the reference's own module produced (values + autograd gradients).
+# ------------------------------------------------------------------------------------------------------------------
+def _bilinear_coords(n_in, n_out):
+    """torch's upsample_bilinear2d with align_corners=True (appearance_network.py:54): source index, neighbour, weight."""
+    scale = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+    src = scale * np.arange(n_out, dtype=np.float32)
+    i0 = src.astype(np.int32)
+    i1 = i0 + (i0 < n_in - 1)
+    l1 = (src - i0.astype(np.float32)).astype(np.float32)
+    return i0, i1, (np.float32(1) - l1).astype(np.float32), l1
+
+
+def bilinear_upsample(x, H, W):
+    y0, y1, wy0, wy1 = _bilinear_coords(x.shape[1], H)
+    x0, x1, wx0, wx1 = _bilinear_coords(x.shape[2], W)
+    top = wx0[None, None, :] * x[:, y0][:, :, x0] + wx1[None, None, :] * x[:, y0][:, :, x1]
+    bot = wx0[None, None, :] * x[:, y1][:, :, x0] + wx1[None, None, :] * x[:, y1][:, :, x1]
+    return (wy0[None, :, None] * top + wy1[None, :, None] * bot).astype(np.float32)
+
+
+def _bilinear_upsample_adjoint(g, h, w):
+    C, H, W = g.shape
+    y0, y1, wy0, wy1 = _bilinear_coords(h, H)
+    x0, x1, wx0, wx1 = _bilinear_coords(w, W)
+    out = np.zeros((C, h, w), np.float64)
+    for (yi, wy) in ((y0, wy0), (y1, wy1)):
+        for (xi, wx) in ((x0, wx0), (x1, wx1)):
+            contrib = g.astype(np.float64) * wy[None, :, None] * wx[None, None, :]
+            np.add.at(out, (slice(None), yi[:, None], xi[None, :]), contrib)
+    return out.astype(np.float32)
+
+
+def _conv3x3(x, w, b):
+    """Conv2d(k=3, stride 1, padding 1): x [Ci,H,W], w [Co,Ci,3,3], b [Co]."""
+    Ci, H, W = x.shape
+    xp = np.zeros((Ci, H + 2, W + 2), np.float32)
+    xp[:, 1:-1, 1:-1] = x
+    out = np.zeros((w.shape[0], H, W), np.float32)
+    for dy in range(3):
+        for dx in range(3):
+            out += np.einsum("oc,chw->ohw", w[:, :, dy, dx], xp[:, dy:dy + H, dx:dx + W], optimize=True).astype(np.float32)
+    return out + b[:, None, None]
+
+
+def _conv3x3_backward(x, w, gz):
+    """Gradients of _conv3x3 w.r.t. x, w, b given gz = dL/dout."""
+    Ci, H, W = x.shape
+    xp = np.zeros((Ci, H + 2, W + 2), np.float32)
+    xp[:, 1:-1, 1:-1] = x
+    gp = np.zeros((gz.shape[0], H + 2, W + 2), np.float32)
+    gp[:, 1:-1, 1:-1] = gz
+    gw = np.zeros_like(w)
+    gx = np.zeros((Ci, H, W), np.float32)
+    for dy in range(3):
+        for dx in range(3):
+            gw[:, :, dy, dx] = np.einsum("ohw,chw->oc", gz.astype(np.float64), xp[:, dy:dy + H, dx:dx + W].astype(np.float64))
+            gx += np.einsum("oc,ohw->chw", w[:, :, dy, dx], gp[:, 2 - dy:2 - dy + H, 2 - dx:2 - dx + W], optimize=True).astype(np.float32)
+    return gx, gw, gz.astype(np.float64).sum(axis=(1, 2)).astype(np.float32)
+
+
+def appearance_tail_forward(feat, w2, b2, w3, b3, image):
+    """feat = output of `up4` [16,h,w]; returns (mapping_image, transformed_image, saved) -- appearance_network.py:54-60,15."""
+    feat, w2, b2, w3, b3, image = (np.ascontiguousarray(t, np.float32) for t in (feat, w2, b2, w3, b3, image))
+    H, W = image.shape[1:]
+    u = bilinear_upsample(feat, H, W)
+    a = np.maximum(_conv3x3(u, w2, b2), np.float32(0))
+    z = _conv3x3(a, w3, b3)
+    m = (np.float32(1) / (np.float32(1) + np.exp(-z))).astype(np.float32)
+    return m, (m * image).astype(np.float32), dict(u=u, a=a, m=m, feat_shape=feat.shape)
+
+
+def appearance_tail_backward(saved, w2, w3, image, g_transformed, g_mapping=None):
+    """Returns dict of gradients: feat, w2, b2, w3, b3, image (the direct `mapping * g` term only: the path through the
+    down-sampled input of the network is upstream of `feat`)."""
+    u, a, m = saved["u"], saved["a"], saved["m"]
+    g = np.ascontiguousarray(g_transformed, np.float32)
+    dm = g * image if g_mapping is None else g * image + g_mapping
+    dz3 = (dm * m * (np.float32(1) - m)).astype(np.float32)
+    da, gw3, gb3 = _conv3x3_backward(a, w3, dz3)
+    dz2 = np.where(a > 0, da, np.float32(0)).astype(np.float32)
+    du, gw2, gb2 = _conv3x3_backward(u, w2, dz2)
+    _, h, w = saved["feat_shape"]
+    return dict(feat=_bilinear_upsample_adjoint(du, h, w), w2=gw2, b2=gb2, w3=gw3, b3=gb3, image=(g * m).astype(np.float32))

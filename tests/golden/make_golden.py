@@ -120,6 +120,52 @@ def ref_loss_decoupled():
     np.savez_compressed(os.path.join(HERE, "ref_loss_decoupled.npz"), **out)
 
 
+def ref_appearance():
+    """scene/ptgs/appearance_network.py run as is (decouple_appearance on a stand-in `gaussians` holding the embedding and the
+    network): the full-resolution tail's inputs (output of `up4`, conv2/conv3 parameters, image), outputs and autograd
+    gradients.  The gradient of the image is split into the direct `mapping * g` term and the path through the network input."""
+    an = _load("ref_appearance_network", "scene/ptgs/appearance_network.py")
+    out = {}
+    k = 0
+    for seed, (H, W) in enumerate([(40, 72), (70, 101)]):
+        torch.manual_seed(100 + seed)
+        net = an.AppearanceNetwork(3 + 64, 3)
+        with torch.no_grad():  # default init gives a nearly constant sigmoid: widen the last layers so every term matters
+            net.conv2.weight.mul_(3.0); net.conv3.weight.mul_(6.0); net.conv2.bias.add_(0.1 * torch.randn(16))
+
+        class G:
+            appearance_network = net
+            emb = (0.5 * torch.randn(4, 64)).requires_grad_(True)
+
+            def get_apperance_embedding(self, idx):
+                return self.emb[idx]
+
+        kept = {}
+        def keep(mod, inp, o):
+            o.retain_grad()
+            kept["feat"] = o
+
+        hook = net.up4.register_forward_hook(keep)
+        image = torch.rand(3, H, W).requires_grad_(True)
+        r1, r2 = torch.randn(3, H, W), torch.randn(3, H, W)
+        transformed, mapping = an.decouple_appearance(image, G(), 2)
+        ((transformed * r1).sum() + (mapping * r2).sum()).backward(retain_graph=True)
+        hook.remove()
+        feat = kept["feat"]
+        g_feat = feat.grad.clone()  # (the retained .grad accumulates again under the next call)
+        via_input = torch.autograd.grad(feat, image, grad_outputs=g_feat)[0]
+        out.update({f"feat{k}": feat.detach()[0].numpy(), f"image{k}": image.detach().numpy(), f"r1_{k}": r1.numpy(), f"r2_{k}": r2.numpy(),
+                    f"w2_{k}": net.conv2.weight.detach().numpy(), f"b2_{k}": net.conv2.bias.detach().numpy(),
+                    f"w3_{k}": net.conv3.weight.detach().numpy(), f"b3_{k}": net.conv3.bias.detach().numpy(),
+                    f"mapping{k}": mapping.detach().numpy(), f"transformed{k}": transformed.detach().numpy(),
+                    f"g_feat{k}": g_feat[0].numpy(), f"g_w2_{k}": net.conv2.weight.grad.numpy(), f"g_b2_{k}": net.conv2.bias.grad.numpy(),
+                    f"g_w3_{k}": net.conv3.weight.grad.numpy(), f"g_b3_{k}": net.conv3.bias.grad.numpy(),
+                    f"g_image_direct{k}": (image.grad - via_input).numpy()})
+        k += 1
+    out["n"] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, "ref_appearance.npz"), **out)
+
+
 def _h(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
@@ -162,6 +208,7 @@ if __name__ == "__main__":
     ref_cameras()
     ref_loss()
     ref_loss_decoupled()
+    ref_appearance()
     oracle_snapshot()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,175 @@
+"""Appearance-decoupling tail: scene/ptgs/appearance_network.py:54-60 + :15.
+
+PINNED by the reference itself: tests/golden/ref_appearance.npz came from running its own AppearanceNetwork /
+decouple_appearance (values + autograd gradients, make_golden.py ref_appearance).  CPU tests check the numpy oracle against it;
+GPU tests check the HIP kernels against the fixture, against the oracle at awkward and full sizes, and the whole
+`decouple_appearance` against the same layers run as stock torch ops.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GRADS = (("feat", "g_feat{k}"), ("w2", "g_w2_{k}"), ("b2", "g_b2_{k}"), ("w3", "g_w3_{k}"), ("b3", "g_b3_{k}"), ("image", "g_image_direct{k}"))
+
+
+def test_oracle_matches_reference_appearance_network():
+    fx = np.load(os.path.join(G, "ref_appearance.npz"))
+    for k in range(int(fx["n"])):
+        m, t, saved = oracle.appearance_tail_forward(fx[f"feat{k}"], fx[f"w2_{k}"], fx[f"b2_{k}"], fx[f"w3_{k}"], fx[f"b3_{k}"], fx[f"image{k}"])
+        assert np.abs(m - fx[f"mapping{k}"]).max() < 5e-7 and np.abs(t - fx[f"transformed{k}"]).max() < 5e-7
+        g = oracle.appearance_tail_backward(saved, fx[f"w2_{k}"], fx[f"w3_{k}"], fx[f"image{k}"], fx[f"r1_{k}"], fx[f"r2_{k}"])
+        for name, key in GRADS:
+            want = fx[key.format(k=k)]
+            assert np.abs(g[name] - want).max() <= 5e-6 * np.abs(want).max(), name
+
+
+def test_oracle_bilinear_is_torchs():
+    import torch.nn.functional as F
+
+    x = torch.randn(3, 5, 7, generator=torch.Generator().manual_seed(0))
+    for (H, W) in [(12, 17), (5, 7), (1, 1), (33, 8)]:
+        want = F.interpolate(x[None], size=(H, W), mode="bilinear", align_corners=True)[0].numpy()
+        assert np.abs(oracle.bilinear_upsample(x.numpy(), H, W) - want).max() < 1e-6
+
+
+def _run_hip(feat, w2, b2, w3, b3, image, r1, r2):
+    from based_on_point_cloud_partitions_amd.appearance import appearance_tail
+
+    t = lambda a: torch.tensor(a, device="cuda", requires_grad=True)
+    ins = [t(a) for a in (feat, w2, b2, w3, b3, image)]
+    transformed, mapping = appearance_tail(*ins)
+    loss = (transformed * torch.tensor(r1, device="cuda")).sum()
+    if r2 is not None:
+        loss = loss + (mapping * torch.tensor(r2, device="cuda")).sum()
+    H, W = image.shape[1:]
+    saved_a = transformed.grad_fn.saved_tensors[5].view(torch.float32).view(16, H, W).cpu().numpy()  # relu(conv2) as the kernels kept it
+    loss.backward()
+    names = ("feat", "w2", "b2", "w3", "b3", "image")
+    grads = {n: v.grad.cpu().numpy() for n, v in zip(names, ins)}
+    grads["saved_a"] = saved_a
+    return mapping.detach().cpu().numpy(), transformed.detach().cpu().numpy(), grads
+
+
+@pytest.mark.gpu
+def test_hip_tail_matches_reference_fixture():
+    fx = np.load(os.path.join(G, "ref_appearance.npz"))
+    for k in range(int(fx["n"])):
+        m, t, g = _run_hip(fx[f"feat{k}"], fx[f"w2_{k}"], fx[f"b2_{k}"], fx[f"w3_{k}"], fx[f"b3_{k}"], fx[f"image{k}"], fx[f"r1_{k}"], fx[f"r2_{k}"])
+        assert np.abs(m - fx[f"mapping{k}"]).max() < 1e-6 and np.abs(t - fx[f"transformed{k}"]).max() < 1e-6
+        for name, key in GRADS:
+            want = fx[key.format(k=k)]
+            assert np.abs(g[name] - want).max() <= 1e-5 * np.abs(want).max(), (k, name)
+
+
+def _random_case(H, W, fh, fw, seed):
+    rng = np.random.default_rng(seed)
+    f32 = lambda a: a.astype(np.float32)
+    feat = f32(np.maximum(rng.normal(0.2, 1.0, (16, fh, fw)), 0))  # up4 ends in a ReLU
+    w2, b2 = f32(rng.normal(0, 0.25, (16, 16, 3, 3))), f32(rng.normal(0, 0.3, 16))
+    w3, b3 = f32(rng.normal(0, 0.3, (3, 16, 3, 3))), f32(rng.normal(0, 0.3, 3))
+    return feat, w2, b2, w3, b3, f32(rng.uniform(0, 1, (3, H, W))), f32(rng.normal(0, 1, (3, H, W))), f32(rng.normal(0, 1, (3, H, W)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,fh,fw,with_r2", [(33, 65, 16, 32, True), (16, 64, 16, 16, True), (8, 64, 16, 32, False), (17, 130, 1, 64, True),
+                                                (9, 7, 3, 1, True), (1, 1, 1, 1, False), (131, 257, 64, 128, True), (1080, 1920, 528, 960, False)])
+def test_hip_tail_matches_oracle(H, W, fh, fw, with_r2):
+    feat, w2, b2, w3, b3, image, r1, r2 = _random_case(H, W, fh, fw, H * 1000 + W)
+    if not with_r2:
+        r2 = None
+    m, t, g = _run_hip(feat, w2, b2, w3, b3, image, r1, r2)
+    want_m, want_t, saved = oracle.appearance_tail_forward(feat, w2, b2, w3, b3, image)
+    assert np.abs(m - want_m).max() < 2e-6 and np.abs(t - want_t).max() < 2e-6
+    # the ReLU mask is a discontinuity: a pre-activation within rounding of 0 may fall on either side (at 1080p there are 33 M of
+    # them), so the oracle's backward runs on the activations the kernels saved, after checking those against its own
+    assert np.abs(g["saved_a"] - saved["a"]).max() <= 1e-5 * max(1.0, np.abs(saved["a"]).max())
+    saved["a"] = g["saved_a"]
+    want = oracle.appearance_tail_backward(saved, w2, w3, image, r1, r2)
+    for name in ("feat", "w2", "b2", "w3", "b3", "image"):
+        scale = max(np.abs(want[name]).max(), 1e-6)
+        assert np.abs(g[name] - want[name]).max() <= 2e-5 * scale, (name, np.abs(g[name] - want[name]).max(), scale)
+
+
+class _Net(torch.nn.Module):
+    """Same layers and attribute names as the reference's AppearanceNetwork (appearance_network.py:31-61), as stock torch ops."""
+
+    class _Up(torch.nn.Module):
+        def __init__(self, ci, co):
+            super().__init__()
+            self.pixel_shuffle, self.conv, self.relu = torch.nn.PixelShuffle(2), torch.nn.Conv2d(ci // 4, co, 3, padding=1), torch.nn.ReLU()
+
+        def forward(self, x):
+            return self.relu(self.conv(self.pixel_shuffle(x)))
+
+    def __init__(self):
+        super().__init__()
+        C = torch.nn.Conv2d
+        self.conv1, self.up1, self.up2, self.up3, self.up4 = C(67, 256, 3, padding=1), self._Up(256, 128), self._Up(128, 64), self._Up(64, 32), self._Up(32, 16)
+        self.conv2, self.conv3, self.relu, self.sigmoid = C(16, 16, 3, padding=1), C(16, 3, 3, padding=1), torch.nn.ReLU(), torch.nn.Sigmoid()
+
+    def forward(self, x, H, W):
+        x = self.up4(self.up3(self.up2(self.up1(self.relu(self.conv1(x))))))
+        x = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=True)
+        return self.sigmoid(self.conv3(self.relu(self.conv2(x))))
+
+
+class _Gaussians:
+    def __init__(self, seed):
+        torch.manual_seed(seed)
+        self.appearance_network = _Net().cuda()
+        with torch.no_grad():
+            self.appearance_network.conv2.weight.mul_(3.0)
+            self.appearance_network.conv3.weight.mul_(6.0)
+        self._emb = torch.nn.Parameter((0.5 * torch.randn(5, 64)).cuda())
+
+    def get_apperance_embedding(self, idx):
+        return self._emb[idx]
+
+
+@pytest.mark.gpu
+def test_decouple_appearance_matches_the_stock_torch_dataflow():
+    """The whole function (head as the module's own layers + HIP tail) against appearance_network.py:7-17 with every layer a torch
+    op, on the GPU: outputs, and the gradients of the image (both paths), the embedding and every network parameter."""
+    import torch.nn.functional as F
+
+    from based_on_point_cloud_partitions_amd.appearance import decouple_appearance
+
+    H, W = 200, 333
+    a, b = _Gaussians(3), _Gaussians(3)
+    img = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    r = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).cuda()
+    ia, ib = img.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    ta, ma = decouple_appearance(ia, a, 3)
+    emb = b.get_apperance_embedding(3)
+    down = F.interpolate(ib[None], size=(H // 32, W // 32), mode="bilinear", align_corners=True)[0]
+    x = torch.cat([down, emb[None].repeat(H // 32, W // 32, 1).permute(2, 0, 1)], dim=0)[None]
+    mb = b.appearance_network(x, H, W).squeeze()
+    tb = mb * ib
+    assert ta.shape == tb.shape == (3, H, W) and ma.shape == mb.shape
+    assert (ta - tb).abs().max().item() < 2e-6 and (ma - mb).abs().max().item() < 2e-6
+    (ta * r).sum().backward()
+    (tb * r).sum().backward()
+    close = lambda u, v: (u - v).abs().max().item() <= 2e-4 * max(v.abs().max().item(), 1e-6)
+    assert close(ia.grad, ib.grad) and close(a._emb.grad, b._emb.grad)
+    for (n, pa), (_, pb) in zip(a.appearance_network.named_parameters(), b.appearance_network.named_parameters()):
+        assert close(pa.grad, pb.grad), n
+
+
+@pytest.mark.gpu
+def test_appearance_tail_rejects_cpu_and_wrong_shapes():
+    from based_on_point_cloud_partitions_amd import GsrError
+    from based_on_point_cloud_partitions_amd.appearance import appearance_tail
+
+    feat, w2, b2, w3, b3, image, _, _ = (torch.tensor(a) for a in _random_case(16, 64, 8, 32, 0))
+    with pytest.raises(GsrError):
+        appearance_tail(feat, w2, b2, w3, b3, image)
+    c = lambda t: t.cuda()
+    with pytest.raises(GsrError):
+        appearance_tail(c(feat)[:8], c(w2), c(b2), c(w3), c(b3), c(image))
+    with pytest.raises(GsrError):
+        appearance_tail(c(feat), c(w2)[:, :8].contiguous(), c(b2), c(w3), c(b3), c(image))
