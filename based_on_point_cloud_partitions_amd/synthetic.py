@@ -156,3 +156,54 @@ CONFIGS = {
     "cfg2": dict(P=500_000, W=1920, H=1080, focal=1200.0, cameras=16),
     "cfg4": dict(P=2_000_000, W=1920, H=1080, focal=1200.0, cameras=16),
 }
+
+
+def make_appearance_model(n_cameras=16, seed=0, device="cpu"):
+    """Random-init stand-in for the appearance state train.py:110-111 consumes: `.appearance_network` with the layer shapes and
+    attribute names of the reference's AppearanceNetwork(3 + 64, 3) (scene/ptgs/appearance_network.py:31-61: conv1 67->256, four
+    pixel-shuffle blocks 256->128->64->32->16, bilinear resize, conv2 16->16, conv3 16->3, sigmoid) and
+    `.get_apperance_embedding(idx)` over an [n_cameras, 64] table.  For benchmarks and tests (no checkpoints offline)."""
+    nn = torch.nn
+
+    class Up(nn.Module):
+        def __init__(self, ci, co):
+            super().__init__()
+            self.pixel_shuffle, self.conv, self.relu = nn.PixelShuffle(2), nn.Conv2d(ci // 4, co, 3, padding=1), nn.ReLU()
+
+        def forward(self, x):
+            return self.relu(self.conv(self.pixel_shuffle(x)))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(67, 256, 3, padding=1)
+            self.up1, self.up2, self.up3, self.up4 = Up(256, 128), Up(128, 64), Up(64, 32), Up(32, 16)
+            self.conv2, self.conv3 = nn.Conv2d(16, 16, 3, padding=1), nn.Conv2d(16, 3, 3, padding=1)
+            self.relu, self.sigmoid = nn.ReLU(), nn.Sigmoid()
+
+        def forward(self, x, H, W):
+            x = self.up4(self.up3(self.up2(self.up1(self.relu(self.conv1(x))))))
+            x = nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=True)
+            return self.sigmoid(self.conv3(self.relu(self.conv2(x))))
+
+    class Model:
+        def __init__(self):
+            torch.manual_seed(seed)
+            self.appearance_network = Net().to(device)
+            self._appearance_embeddings = nn.Parameter((0.5 * torch.randn(n_cameras, 64)).to(device))
+
+        def get_apperance_embedding(self, idx):
+            return self._appearance_embeddings[idx]
+
+    return Model()
+
+
+def decouple_appearance_torch(image, model, view_idx):
+    """The data flow of scene/ptgs/appearance_network.py:7-17 with every layer a stock torch op: the baseline the HIP tail
+    (appearance.py) is timed and tested against."""
+    H, W = image.size(1), image.size(2)
+    emb = model.get_apperance_embedding(view_idx)
+    down = torch.nn.functional.interpolate(image[None], size=(H // 32, W // 32), mode="bilinear", align_corners=True)[0]
+    x = torch.cat([down, emb[None].repeat(H // 32, W // 32, 1).permute(2, 0, 1)], dim=0)[None]
+    mapping = model.appearance_network(x, H, W).squeeze()
+    return mapping * image, mapping

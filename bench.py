@@ -77,8 +77,9 @@ def cpu_baseline(cfg, g, cam, dL):
                       f"forward {t1 - t0:.2f} s + backward {t2 - t1:.2f} s, OpenMP over Gaussians/tiles"}, stats
 
 
-def torch_l1_ssim(img, gt, lam):
-    """Stock-PyTorch evaluation of utils/loss_utils.py + train.py:116-117 (what the reference runs on the GPU), for timing."""
+def torch_l1_ssim(img, gt, lam, l1_image=None):
+    """Stock-PyTorch evaluation of utils/loss_utils.py + train.py:116-117 (what the reference runs on the GPU), for timing.
+    `l1_image`: the image the L1 term is taken on (train.py:112,116: the appearance-decoupled one); default img."""
     import torch.nn.functional as F
     from math import exp
 
@@ -94,7 +95,7 @@ def torch_l1_ssim(img, gt, lam):
     sigma12 = F.conv2d(img * gt, window, padding=5, groups=C) - mu1_mu2
     C1, C2 = 0.01 ** 2, 0.03 ** 2
     ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    return (1.0 - lam) * torch.abs(img - gt).mean() + lam * (1.0 - ssim_map.mean())
+    return (1.0 - lam) * torch.abs((img if l1_image is None else l1_image) - gt).mean() + lam * (1.0 - ssim_map.mean())
 
 
 def full_step_timing(args, rasterizers, g, dL, H, W, dev):
@@ -149,6 +150,29 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
     torch_adam = torch.optim.Adam(groups(), lr=0.0, eps=1e-15)  # scene/gaussian_model.py:175
     hip_adam = HipAdam(groups(), lr=0.0, eps=1e-15)
     hip_l = lambda im: hip_loss.l1_ssim_loss(im, gt, 0.2)
+    # the reference fork's own loss (train.py:110-117): L1 on the appearance-decoupled image, SSIM on the rendered one
+    from based_on_point_cloud_partitions_amd.appearance import decouple_appearance
+    from based_on_point_cloud_partitions_amd.synthetic import decouple_appearance_torch, make_appearance_model
+    app = make_appearance_model(n_cameras=len(rasterizers), seed=3, device=dev)
+    app_params = list(app.appearance_network.parameters()) + [app._appearance_embeddings]
+    app_groups = lambda: [{"params": list(app.appearance_network.parameters()), "lr": 1e-6, "name": "appearance_network"},
+                          {"params": [app._appearance_embeddings], "lr": 1e-6, "name": "appearance_embeddings"}]
+    torch_adam_app = torch.optim.Adam(groups() + app_groups(), lr=0.0, eps=1e-15)
+    hip_adam_app = HipAdam(groups() + app_groups(), lr=0.0, eps=1e-15)
+    view = [0]
+
+    def app_torch_l(im):  # stock torch ops throughout
+        dec, _ = decouple_appearance_torch(im, app, view[0])
+        return torch_l1_ssim(im, gt, 0.2, l1_image=dec)
+
+    def app_mixed_l(im):  # torch network, HIP loss
+        dec, _ = decouple_appearance_torch(im, app, view[0])
+        return hip_loss.l1_ssim_loss(im, gt, 0.2, l1_image=dec)
+
+    def app_hip_l(im):  # HIP tail of the network + HIP loss
+        dec, _ = decouple_appearance(im, app, view[0])
+        return hip_loss.l1_ssim_loss(im, gt, 0.2, l1_image=dec)
+
     variants = (
         ("raster_from_raw_params_reference_dataflow", render_reference, None, None, None),
         ("raster_from_raw_params_fused", render_fused, None, None, None),
@@ -160,6 +184,11 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
         ("train_iteration_hip_rasterizer_torch_activations_hip_loss_torch_adam_torch_stats", render_reference, hip_l, torch_adam,
          stats_reference),
         ("train_iteration_fused_params_hip_loss_hip_adam_hip_stats", render_fused, hip_l, hip_adam, stats_fused),
+        ("train_iteration_with_appearance_reference_dataflow_all_torch", render_reference, app_torch_l, torch_adam_app, stats_reference),
+        ("train_iteration_with_appearance_fused_params_torch_network_hip_loss_hip_adam_hip_stats", render_fused, app_mixed_l, hip_adam_app,
+         stats_fused),
+        ("train_iteration_with_appearance_fused_params_hip_tail_hip_loss_hip_adam_hip_stats", render_fused, app_hip_l, hip_adam_app,
+         stats_fused),
     )
     res = {}
     for name, render, loss, opt, upd in variants:
@@ -168,6 +197,7 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
                 p.copy_(q)
 
         def one(i):
+            view[0] = i % len(rasterizers)
             image, vsp, radii = render(rasterizers[i % len(rasterizers)])
             if loss is None:
                 image.backward(dL)
@@ -180,7 +210,7 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
                 opt.step()  # train.py:155-157
                 opt.zero_grad(set_to_none=True)
             else:
-                for p in params:
+                for p in params + app_params:
                     p.grad = None
         for i in range(4):
             one(i)
@@ -204,9 +234,23 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
         res[name + "_ms"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
         for p in params:
             p.grad = None
+    # the appearance decoupling alone (forward + backward of an L1 on its output), stock torch vs the HIP tail
+    img = torch.rand(3, H, W, device=dev, requires_grad=True)
+    for name, fn in (("appearance_decoupling_torch", decouple_appearance_torch), ("appearance_decoupling_hip_tail", decouple_appearance)):
+        def one_app(i):
+            torch.abs(fn(img, app, i % len(rasterizers))[0] - gt).mean().backward()
+        for i in range(4):
+            one_app(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_app(i)
+        torch.cuda.synchronize()
+        res[name + "_ms"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
     res["note"] = ("per-step ms from GaussianModel's raw parameters (exp/sigmoid/normalize/cat included): raster_* = forward + "
                    "backward with a fixed dL/dcolor; step_with_loss_* add (1-0.2)*L1 + 0.2*(1-SSIM); train_iteration_* add the densification statistics "
-                   "(train.py:140-142) and the Adam step over the six parameter groups (29.5 M parameters); context only, not the headline")
+                   "(train.py:140-142) and the Adam step over the six parameter groups (29.5 M parameters); *_with_appearance_* use the fork's loss of "
+                   "train.py:110-117 (appearance network, L1 on the decoupled image) and step the network's parameters too; context only, not the headline")
     return res
 
 

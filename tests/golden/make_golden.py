@@ -163,6 +163,8 @@ def ref_appearance():
                     f"g_image_direct{k}": (image.grad - via_input).numpy()})
         k += 1
     out["n"] = np.array(k)
+    # the module's parameter names and shapes (what a stand-in network must offer to appearance.py)
+    out["state_keys"] = np.array([f"{name}:{tuple(v.shape)}" for name, v in an.AppearanceNetwork(3 + 64, 3).state_dict().items()])
     np.savez_compressed(os.path.join(HERE, "ref_appearance.npz"), **out)
 
 

@@ -37,6 +37,14 @@ def test_oracle_bilinear_is_torchs():
         assert np.abs(oracle.bilinear_upsample(x.numpy(), H, W) - want).max() < 1e-6
 
 
+def test_synthetic_appearance_model_has_the_reference_modules_parameters():
+    from based_on_point_cloud_partitions_amd.synthetic import make_appearance_model
+
+    fx = np.load(os.path.join(G, "ref_appearance.npz"))
+    mine = [f"{name}:{tuple(v.shape)}" for name, v in make_appearance_model(4).appearance_network.state_dict().items()]
+    assert mine == list(fx["state_keys"])
+
+
 def _run_hip(feat, w2, b2, w3, b3, image, r1, r2):
     from based_on_point_cloud_partitions_amd.appearance import appearance_tail
 
@@ -95,67 +103,37 @@ def test_hip_tail_matches_oracle(H, W, fh, fw, with_r2):
         assert np.abs(g[name] - want[name]).max() <= 2e-5 * scale, (name, np.abs(g[name] - want[name]).max(), scale)
 
 
-class _Net(torch.nn.Module):
-    """Same layers and attribute names as the reference's AppearanceNetwork (appearance_network.py:31-61), as stock torch ops."""
+def _model(seed):
+    from based_on_point_cloud_partitions_amd.synthetic import make_appearance_model
 
-    class _Up(torch.nn.Module):
-        def __init__(self, ci, co):
-            super().__init__()
-            self.pixel_shuffle, self.conv, self.relu = torch.nn.PixelShuffle(2), torch.nn.Conv2d(ci // 4, co, 3, padding=1), torch.nn.ReLU()
-
-        def forward(self, x):
-            return self.relu(self.conv(self.pixel_shuffle(x)))
-
-    def __init__(self):
-        super().__init__()
-        C = torch.nn.Conv2d
-        self.conv1, self.up1, self.up2, self.up3, self.up4 = C(67, 256, 3, padding=1), self._Up(256, 128), self._Up(128, 64), self._Up(64, 32), self._Up(32, 16)
-        self.conv2, self.conv3, self.relu, self.sigmoid = C(16, 16, 3, padding=1), C(16, 3, 3, padding=1), torch.nn.ReLU(), torch.nn.Sigmoid()
-
-    def forward(self, x, H, W):
-        x = self.up4(self.up3(self.up2(self.up1(self.relu(self.conv1(x))))))
-        x = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=True)
-        return self.sigmoid(self.conv3(self.relu(self.conv2(x))))
-
-
-class _Gaussians:
-    def __init__(self, seed):
-        torch.manual_seed(seed)
-        self.appearance_network = _Net().cuda()
-        with torch.no_grad():
-            self.appearance_network.conv2.weight.mul_(3.0)
-            self.appearance_network.conv3.weight.mul_(6.0)
-        self._emb = torch.nn.Parameter((0.5 * torch.randn(5, 64)).cuda())
-
-    def get_apperance_embedding(self, idx):
-        return self._emb[idx]
+    m = make_appearance_model(n_cameras=5, seed=seed, device="cuda")
+    with torch.no_grad():  # the default init gives a nearly constant sigmoid: widen the last layers so every term matters
+        m.appearance_network.conv2.weight.mul_(3.0)
+        m.appearance_network.conv3.weight.mul_(6.0)
+    return m
 
 
 @pytest.mark.gpu
 def test_decouple_appearance_matches_the_stock_torch_dataflow():
     """The whole function (head as the module's own layers + HIP tail) against appearance_network.py:7-17 with every layer a torch
     op, on the GPU: outputs, and the gradients of the image (both paths), the embedding and every network parameter."""
-    import torch.nn.functional as F
-
     from based_on_point_cloud_partitions_amd.appearance import decouple_appearance
 
+    from based_on_point_cloud_partitions_amd.synthetic import decouple_appearance_torch
+
     H, W = 200, 333
-    a, b = _Gaussians(3), _Gaussians(3)
+    a, b = _model(3), _model(3)
     img = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
     r = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).cuda()
     ia, ib = img.clone().requires_grad_(True), img.clone().requires_grad_(True)
     ta, ma = decouple_appearance(ia, a, 3)
-    emb = b.get_apperance_embedding(3)
-    down = F.interpolate(ib[None], size=(H // 32, W // 32), mode="bilinear", align_corners=True)[0]
-    x = torch.cat([down, emb[None].repeat(H // 32, W // 32, 1).permute(2, 0, 1)], dim=0)[None]
-    mb = b.appearance_network(x, H, W).squeeze()
-    tb = mb * ib
+    tb, mb = decouple_appearance_torch(ib, b, 3)
     assert ta.shape == tb.shape == (3, H, W) and ma.shape == mb.shape
     assert (ta - tb).abs().max().item() < 2e-6 and (ma - mb).abs().max().item() < 2e-6
     (ta * r).sum().backward()
     (tb * r).sum().backward()
     close = lambda u, v: (u - v).abs().max().item() <= 2e-4 * max(v.abs().max().item(), 1e-6)
-    assert close(ia.grad, ib.grad) and close(a._emb.grad, b._emb.grad)
+    assert close(ia.grad, ib.grad) and close(a._appearance_embeddings.grad, b._appearance_embeddings.grad)
     for (n, pa), (_, pb) in zip(a.appearance_network.named_parameters(), b.appearance_network.named_parameters()):
         assert close(pa.grad, pb.grad), n
 
