@@ -527,7 +527,7 @@ int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2,
     return check_hip("loss_backward");
 }
 
-size_t gsr_appearance_saved_bytes(int H, int W) { return H > 0 && W > 0 ? (size_t)16 * H * W * sizeof(float) : 0; }
+size_t gsr_appearance_saved_bytes(int H, int W) { return H > 0 && W > 0 ? (size_t)2 * 16 * H * W * sizeof(float) : 0; }  // relu(conv2), u
 
 size_t gsr_appearance_scratch_bytes(int H, int W)
 {

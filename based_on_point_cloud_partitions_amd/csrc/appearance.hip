@@ -13,7 +13,6 @@
 // chosen so that the pixel index is the MFMA column wherever a result is stored (coalesced CHW rows) and the reduction
 // index wherever weights are accumulated.  LDS plane strides are chosen per access pattern (see `plane_base`).
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -55,10 +54,10 @@ __device__ __forceinline__ Lerp lerp_coord(int dst, int n_in, float scale)
 // u tile (halo 1) of `rows` x 64 centre pixels at (ty0, tx0) into LDS planes at plane_off(c); zero outside the image
 template <typename PlaneOff>
 __device__ __forceinline__ void fill_upsampled_tile(float* lds, PlaneOff plane_off, int rows, int ty0, int tx0, int H, int W, int Hh, int Wh,
-                                                    float sy, float sx, const float* __restrict__ feat, int tid)
+                                                    float sy, float sx, const float* __restrict__ feat, float* __restrict__ u_out, int tid)
 {
     const int n = (rows + 2) * RS;
-    const size_t plane = (size_t)Hh * Wh;
+    const size_t plane = (size_t)Hh * Wh, oplane = (size_t)H * W;
     for (int pos = tid; pos < n; pos += 256) {
         const int ry = pos / RS, rx = pos - ry * RS;
         const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
@@ -71,11 +70,14 @@ __device__ __forceinline__ void fill_upsampled_tile(float* lds, PlaneOff plane_o
         const Lerp ly = lerp_coord(y, Hh, sy), lx = lerp_coord(x, Wh, sx);
         const float* p = feat + (size_t)ly.i0 * Wh + lx.i0;
         const int o01 = lx.i1 - lx.i0, o10 = (ly.i1 - ly.i0) * Wh;
+        const bool center = u_out && ry >= 1 && ry <= rows && rx >= 1 && rx <= TW;
 #pragma unroll
         for (int c = 0; c < AC; c++) {
             const float top = lx.l0 * p[0] + lx.l1 * p[o01];
             const float bot = lx.l0 * p[o10] + lx.l1 * p[o10 + o01];
-            dst[plane_off(c)] = ly.l0 * top + ly.l1 * bot;
+            const float u = ly.l0 * top + ly.l1 * bot;
+            dst[plane_off(c)] = u;
+            if (center) u_out[c * oplane + (size_t)y * W + x] = u;
             p += plane;
         }
     }
@@ -115,19 +117,63 @@ __device__ __forceinline__ void fill_tile(float* lds, PlaneOff plane_off, int ro
     }
 }
 
+// A tile in flight: the 16 channel values of NPOS positions per thread, loaded from a CHW tensor while the previous tile is
+// being computed on (tile_fetch), stored to LDS once that is done (tile_commit).  Zero outside the image.
+template <int WIDTH, int NPOS>
+__device__ __forceinline__ void tile_fetch(float (&v)[NPOS][AC], int rows, int y_first, int x_first, int H, int W,
+                                           const float* __restrict__ src, int tid)
+{
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int h = 0; h < NPOS; h++) {
+        const int pos = tid + 256 * h;
+        const int ry = pos / WIDTH, rx = pos - ry * WIDTH;
+        const int y = y_first + ry, x = x_first + rx;
+        const bool in = pos < rows * WIDTH && y >= 0 && y < H && x >= 0 && x < W;
+        const float* p = src + (size_t)(in ? y : 0) * W + (in ? x : 0);
+#pragma unroll
+        for (int c = 0; c < AC; c++) v[h][c] = in ? p[c * plane] : 0.0f;
+    }
+}
+
+template <int WIDTH, int NPOS, typename PlaneOff>
+__device__ __forceinline__ void tile_commit(float* lds, PlaneOff plane_off, const float (&v)[NPOS][AC], int rows, int row_stride, int tid)
+{
+#pragma unroll
+    for (int h = 0; h < NPOS; h++) {
+        const int pos = tid + 256 * h;
+        const int ry = pos / WIDTH, rx = pos - ry * WIDTH;
+        if (pos < rows * WIDTH) {
+#pragma unroll
+            for (int c = 0; c < AC; c++) lds[plane_off(c) + ry * row_stride + rx] = v[h][c];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // 16 -> 16 convolution as 36 MFMAs per 16 pixels: D[out channel][pixel] += W[out][in group of 4] * X[in group of 4][pixel].
-//   DATA_GRAD = false: a = relu(conv(u, w2) + b2), u rebuilt from feat          (appearance_network.py:54-57)
+//   DATA_GRAD = false: a = relu(conv(u, w2) + b2), u rebuilt from feat and also written out for the backward's weight
+//                      gradient                                                     (appearance_network.py:54-57)
 //   DATA_GRAD = true : du = conv^T(dz2, w2)                                        (its autograd)
+// Persistent workgroups over 8 x 64 tiles.  While a tile's 288 MFMAs per wave run, the next tile's input is already on its
+// way into registers: for the data gradient the halo tile itself, for the forward the patch of `feat` under the tile (8 x 36
+// source pixels when the scale is about 1/2: `staged`), which is then parked in LDS and interpolated from there.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int PS8 = 688;  // >= 10 * 66, = 16 mod 32: planes 16 banks apart for "4 channel planes x 16 pixels" operand reads
+constexpr int ST_ROWS = 8, ST_COLS = 36, ST_POS = ST_ROWS * ST_COLS, ST_PER_THREAD = AC * ST_POS / 256;
+inline bool upsample_staged_ok(float sy, float sx) { return sy <= 0.55f && sx <= 0.51f; }  // 9 sy + 2 <= 8, 65 sx + 2 <= 36
+
 template <bool DATA_GRAD>
 __global__ __launch_bounds__(256) void app_conv16_kernel(int H, int W, int Hh, int Wh, float sy, float sx, int tiles_x, int n_tiles,
-                                                         const float* __restrict__ src, const float* __restrict__ w2,
-                                                         const float* __restrict__ b2, float* __restrict__ out, int dbg)
+                                                         int staged, const float* __restrict__ src, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, float* __restrict__ out,
+                                                         float* __restrict__ u_out)
 {
-    __shared__ float lds[AC * PS_BIG];
+    __shared__ float lds[AC * PS8];
+    __shared__ float stage[DATA_GRAD ? 1 : AC * ST_POS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, k = lane >> 4;
-    auto plane_off = [](int c) { return c * PS_BIG; };
+    auto plane_off = [](int c) { return c * PS8; };
+    const size_t plane = (size_t)H * W, hplane = (size_t)Hh * Wh;
     // A operands: lane (row n, k) of step (tap t, group j) holds W[n][4j + k] for that tap
     float wreg[36];
 #pragma unroll
@@ -139,21 +185,81 @@ __global__ __launch_bounds__(256) void app_conv16_kernel(int H, int W, int Hh, i
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) bias[r] = DATA_GRAD ? 0.0f : b2[4 * k + r];
-    const float* bbase = lds + k * PS_BIG + n;
-    const size_t plane = (size_t)H * W;
-    // persistent: the weights are loaded once per workgroup, which then walks tiles blockIdx.x, + gridDim.x, ...
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int ty0 = (tile / tiles_x) * TH_BIG, tx0 = (tile % tiles_x) * TW;
-    __syncthreads();  // the previous tile's readers are done
-    if (!(dbg & 1)) {
-        if (DATA_GRAD)
-            fill_tile<RS>(lds, plane_off, TH_BIG + 2, RS, ty0 - 1, tx0 - 1, H, W, src, tid);
-        else
-            fill_upsampled_tile(lds, plane_off, TH_BIG, ty0, tx0, H, W, Hh, Wh, sy, sx, src, tid);
-    }
-    __syncthreads();
-    if (dbg & 2) continue;
-    // B operands of one tap (4 channel groups x 4 segments of 16 pixels) are fetched one tap ahead of the MFMAs using them
+
+    float pre[DATA_GRAD ? 3 : 1][AC];        // data gradient: the next halo tile (660 positions)
+    float pre_f[DATA_GRAD ? 1 : ST_PER_THREAD];  // forward: the next patch of feat
+    auto tile_origin = [&](int tile, int& ty0, int& tx0) { ty0 = (tile / tiles_x) * TH_SMALL; tx0 = (tile % tiles_x) * TW; };
+    auto patch_origin = [&](int ty0, int tx0, int& ry0, int& rx0) {
+        ry0 = lerp_coord(max(ty0 - 1, 0), Hh, sy).i0;
+        rx0 = lerp_coord(max(tx0 - 1, 0), Wh, sx).i0;
+    };
+    auto fetch = [&](int tile) {
+        int ty0, tx0;
+        tile_origin(tile, ty0, tx0);
+        if constexpr (DATA_GRAD) {
+            tile_fetch<RS, 3>(pre, TH_SMALL + 2, ty0 - 1, tx0 - 1, H, W, src, tid);
+        } else if (staged) {
+            int ry0, rx0;
+            patch_origin(ty0, tx0, ry0, rx0);
+#pragma unroll
+            for (int i = 0; i < ST_PER_THREAD; i++) {
+                const int idx = tid + 256 * i, c = idx / ST_POS, p = idx - c * ST_POS, ry = p / ST_COLS, rx = p - ry * ST_COLS;
+                pre_f[i] = src[c * hplane + (size_t)min(ry0 + ry, Hh - 1) * Wh + min(rx0 + rx, Wh - 1)];
+            }
+        }
+    };
+    auto commit = [&](int tile) {
+        int ty0, tx0;
+        tile_origin(tile, ty0, tx0);
+        if constexpr (DATA_GRAD) {
+            tile_commit<RS, 3>(lds, plane_off, pre, TH_SMALL + 2, RS, tid);
+        } else if (!staged) {
+            fill_upsampled_tile(lds, plane_off, TH_SMALL, ty0, tx0, H, W, Hh, Wh, sy, sx, src, u_out, tid);
+        } else {
+            int ry0, rx0;
+            patch_origin(ty0, tx0, ry0, rx0);
+#pragma unroll
+            for (int i = 0; i < ST_PER_THREAD; i++) stage[tid + 256 * i] = pre_f[i];
+            __syncthreads();
+            for (int pos = tid; pos < (TH_SMALL + 2) * RS; pos += 256) {
+                const int ry = pos / RS, rx = pos - ry * RS;
+                const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
+                float* dst = lds + pos;
+                if (y < 0 || y >= H || x < 0 || x >= W) {
+#pragma unroll
+                    for (int c = 0; c < AC; c++) dst[c * PS8] = 0.0f;
+                    continue;
+                }
+                const Lerp ly = lerp_coord(y, Hh, sy), lx = lerp_coord(x, Wh, sx);
+                const float* p = stage + (ly.i0 - ry0) * ST_COLS + (lx.i0 - rx0);
+                const int o01 = lx.i1 - lx.i0, o10 = (ly.i1 - ly.i0) * ST_COLS;
+                const bool center = ry >= 1 && ry <= TH_SMALL && rx >= 1 && rx <= TW;
+#pragma unroll
+                for (int c = 0; c < AC; c++) {
+                    const float top = lx.l0 * p[0] + lx.l1 * p[o01];
+                    const float bot = lx.l0 * p[o10] + lx.l1 * p[o10 + o01];
+                    const float u = ly.l0 * top + ly.l1 * bot;
+                    dst[c * PS8] = u;
+                    if (center) u_out[c * plane + (size_t)y * W + x] = u;
+                    p += ST_POS;
+                }
+            }
+        }
+    };
+    // one 16-pixel segment of finished accumulators -> bias, ReLU (forward), CHW store
+    auto store_segment = [&](const f32x4& acc, int y, int x) {
+        if (y < H && x < W) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                float v = acc[reg] + bias[reg];
+                if (!DATA_GRAD) v = fmaxf(v, 0.0f);
+                out[(4 * k + reg) * plane + (size_t)y * W + x] = v;
+            }
+        }
+    };
+
+    const float* bbase = lds + k * PS8 + n;
+    // B operands of one tap (4 channel groups x 4 segments of 16 pixels) are read one tap ahead of the MFMAs using them
     auto load_tap = [&](float(&b)[16], int row, int t) {
         const int dy = t / 3, dx = t % 3;
         // forward reads x[q + (dy-1, dx-1)]; the data gradient reads dz[q - (dy-1, dx-1)]; tile origin is (-1, -1)
@@ -161,49 +267,51 @@ __global__ __launch_bounds__(256) void app_conv16_kernel(int H, int W, int Hh, i
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) b[j * 4 + s] = bbase[4 * j * PS_BIG + (row + oy) * RS + s * 16 + ox];
+            for (int s = 0; s < 4; s++) b[j * 4 + s] = bbase[4 * j * PS8 + (row + oy) * RS + s * 16 + ox];
     };
-    float bq[2][16];
-    load_tap(bq[0], wave * 4, 0);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = wave * 4 + r;
-        f32x4 acc[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const int step = r * 9 + t;
-            if (step + 1 < 36) load_tap(bq[(step + 1) & 1], wave * 4 + (step + 1) / 9, (step + 1) % 9);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int s = 0; s < 4; s++)
-                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t * 4 + j], bq[step & 1][j * 4 + s], acc[s], 0, 0, 0);
-            // keep the schedule as written: this tap's MFMAs interleaved with the next tap's LDS reads, nothing moved across taps
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int y = ty0 + row;
-        if (y < H) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int x = tx0 + s * 16 + n;
-                if (x < W) {
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        float v = acc[s][reg] + bias[reg];
-                        if (!DATA_GRAD) v = fmaxf(v, 0.0f);
-                        out[(4 * k + reg) * plane + (size_t)y * W + x] = v;
-                    }
-                }
-            }
-        }
+
+    if ((int)blockIdx.x < n_tiles) {
+        fetch(blockIdx.x);
+        commit(blockIdx.x);
     }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int ty0, tx0;
+        tile_origin(tile, ty0, tx0);
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) fetch(next);
+        float bq[2][16];
+        f32x4 acc[2][4];
+        load_tap(bq[0], wave * 2, 0);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) acc[r][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int step = r * 9 + t;
+                if (step + 1 < 18) load_tap(bq[(step + 1) & 1], wave * 2 + (step + 1) / 9, (step + 1) % 9);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+                        acc[r][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t * 4 + j], bq[step & 1][j * 4 + s], acc[r][s], 0, 0, 0);
+                // the first row's results leave while the second row's MFMAs run
+                if (r == 1 && t >= 1 && t <= 4) store_segment(acc[0][t - 1], ty0 + wave * 2, tx0 + (t - 1) * 16 + n);
+                // keep the schedule as written: this tap's MFMAs interleaved with the next tap's LDS reads
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) store_segment(acc[1][s], ty0 + wave * 2 + 1, tx0 + s * 16 + n);
+        __syncthreads();  // every wave is done reading this tile
+        if (next < n_tiles) commit(next);
+        __syncthreads();
     }
 }
 
@@ -211,7 +319,7 @@ __global__ __launch_bounds__(256) void app_conv16_kernel(int H, int W, int Hh, i
 // m = sigmoid(conv3x3(a, w3) + b3), t = m * image   (appearance_network.py:58-60, :15).  3 output channels: VALU, 4 pixels
 // per thread, weights broadcast from LDS.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void app_conv3_fwd_kernel(int H, int W, int tiles_x, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void app_conv3_fwd_kernel(int H, int W, int tiles_x, int n_tiles, const float* __restrict__ a,
                                                             const float* __restrict__ w3, const float* __restrict__ b3,
                                                             const float* __restrict__ image, float* __restrict__ mapping,
                                                             float* __restrict__ transformed)
@@ -219,51 +327,75 @@ __global__ __launch_bounds__(256) void app_conv3_fwd_kernel(int H, int W, int ti
     __shared__ float lds[AC * PS_BIG];
     __shared__ float4 wl[AC * 9];  // [ci][dy][dx] -> the three output channels' weights
     const int tid = threadIdx.x;
-    const int ty0 = (blockIdx.x / tiles_x) * TH_BIG, tx0 = (blockIdx.x % tiles_x) * TW;
+    auto plane_off = [](int c) { return c * PS_BIG; };
     if (tid < AC * 9) wl[tid] = float4{w3[tid], w3[AC * 9 + tid], w3[2 * AC * 9 + tid], 0.0f};
-    fill_tile<RS>(lds, [](int c) { return c * PS_BIG; }, TH_BIG + 2, RS, ty0 - 1, tx0 - 1, H, W, a, tid);
-    __syncthreads();
+    const float bias[AO] = {b3[0], b3[1], b3[2]};
     const int row = tid >> 4, xs = (tid & 15) * 4;
-    float acc[4][AO];
+    const size_t plane = (size_t)H * W;
+    // persistent over 16 x 64 tiles; the next tile (18 x 66 with its halo) travels in registers during the FMAs of this one
+    float pre[5][AC];
+    auto fetch = [&](int tile) {
+        tile_fetch<RS, 5>(pre, TH_BIG + 2, (tile / tiles_x) * TH_BIG - 1, (tile % tiles_x) * TW - 1, H, W, a, tid);
+    };
+    if ((int)blockIdx.x < n_tiles) {
+        fetch(blockIdx.x);
+        tile_commit<RS, 5>(lds, plane_off, pre, TH_BIG + 2, RS, tid);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int ty0 = (tile / tiles_x) * TH_BIG, tx0 = (tile % tiles_x) * TW;
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) fetch(next);
+        // this thread's 4 x 3 image values: requested now, used after the FMAs
+        const int y = ty0 + row;
+        float img[4][AO];
 #pragma unroll
-    for (int p = 0; p < 4; p++)
+        for (int p = 0; p < 4; p++)
 #pragma unroll
-        for (int co = 0; co < AO; co++) acc[p][co] = 0.0f;
-#pragma unroll 4
-    for (int c = 0; c < AC; c++) {
+            for (int co = 0; co < AO; co++) {
+                const bool in = y < H && tx0 + xs + p < W;
+                img[p][co] = in ? image[co * plane + (size_t)y * W + tx0 + xs + p] : 0.0f;
+            }
+        float acc[4][AO];
 #pragma unroll
-        for (int dy = 0; dy < 3; dy++) {
-            const float2* p2 = reinterpret_cast<const float2*>(lds + c * PS_BIG + (row + dy) * RS + xs);
-            const float2 v01 = p2[0], v23 = p2[1], v45 = p2[2];
-            const float v[6] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y};
+        for (int p = 0; p < 4; p++)
 #pragma unroll
-            for (int dx = 0; dx < 3; dx++) {
-                const float4 w = wl[(c * 3 + dy) * 3 + dx];
+            for (int co = 0; co < AO; co++) acc[p][co] = 0.0f;
+#pragma unroll 2
+        for (int c = 0; c < AC; c++) {
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    acc[p][0] = __builtin_fmaf(w.x, v[p + dx], acc[p][0]);
-                    acc[p][1] = __builtin_fmaf(w.y, v[p + dx], acc[p][1]);
-                    acc[p][2] = __builtin_fmaf(w.z, v[p + dx], acc[p][2]);
+            for (int dy = 0; dy < 3; dy++) {
+                const float2* p2 = reinterpret_cast<const float2*>(lds + c * PS_BIG + (row + dy) * RS + xs);
+                const float2 v01 = p2[0], v23 = p2[1], v45 = p2[2];
+                const float v[6] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y};
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    const float4 w = wl[(c * 3 + dy) * 3 + dx];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        acc[p][0] = __builtin_fmaf(w.x, v[p + dx], acc[p][0]);
+                        acc[p][1] = __builtin_fmaf(w.y, v[p + dx], acc[p][1]);
+                        acc[p][2] = __builtin_fmaf(w.z, v[p + dx], acc[p][2]);
+                    }
                 }
             }
         }
-    }
-    const int y = ty0 + row;
-    if (y >= H) return;
-    const size_t plane = (size_t)H * W;
 #pragma unroll
-    for (int co = 0; co < AO; co++) {
-        const float bias = b3[co];
+        for (int co = 0; co < AO; co++) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int x = tx0 + xs + p;
-            if (x < W) {
-                const size_t o = co * plane + (size_t)y * W + x;
-                const float m = gsr_sigmoidf(acc[p][co] + bias);
-                mapping[o] = m;
-                transformed[o] = m * image[o];
+            for (int p = 0; p < 4; p++) {
+                const int x = tx0 + xs + p;
+                const float m = gsr_sigmoidf(acc[p][co] + bias[co]);
+                if (y < H && x < W) {
+                    const size_t o = co * plane + (size_t)y * W + x;
+                    mapping[o] = m;
+                    transformed[o] = m * img[p][co];
+                }
             }
         }
+        __syncthreads();  // every wave is done reading this tile
+        if (next < n_tiles) tile_commit<RS, 5>(lds, plane_off, pre, TH_BIG + 2, RS, tid);
+        __syncthreads();
     }
 }
 
@@ -314,33 +446,61 @@ __global__ __launch_bounds__(256) void app_conv3_bwd_kernel(int H, int W, int ti
     float bsum2[4] = {0.f, 0.f, 0.f, 0.f};
     float bsum3[AO] = {0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // the next tile travels in registers while this one is computed: relu(conv2) for the centre pixels, and the three
+    // per-pixel inputs of dz3 (upstream gradient(s), image, mapping) for the centre and its halo
+    auto a_off = [](int c) { return plane_base(c, PS_CENTER); };
+    float pre_a[2][AC];
+    float pre_g[3][AO], pre_i[3][AO], pre_m[3][AO], pre_gm[3][AO];
+    auto fetch = [&](int tile) {
         const int ty0 = (tile / tiles_x) * TH_SMALL, tx0 = (tile % tiles_x) * TW;
-        __syncthreads();  // previous tile's readers are done
-        fill_tile<TW>(a_lds, [](int c) { return plane_base(c, PS_CENTER); }, TH_SMALL, TW, ty0, tx0, H, W, a, tid);
-        for (int pos = tid; pos < PS_DZ3; pos += 256) {
-            const int ry = pos / RS, rx = pos - ry * RS;
+        tile_fetch<TW, 2>(pre_a, TH_SMALL, ty0, tx0, H, W, a, tid);
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+            const int pos = tid + 256 * h, ry = pos / RS, rx = pos - ry * RS;
             const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
-            const bool in = y >= 0 && y < H && x >= 0 && x < W;
-            const bool center = ry >= 1 && ry <= TH_SMALL && rx >= 1 && rx <= TW;
+            const bool in = pos < PS_DZ3 && y >= 0 && y < H && x >= 0 && x < W;
+            const size_t o = in ? (size_t)y * W + x : 0;
 #pragma unroll
             for (int co = 0; co < AO; co++) {
-                float dz = 0.0f;
-                if (in) {
-                    const size_t o = co * plane + (size_t)y * W + x;
-                    const float g = g_t[o], m = mapping[o];
-                    float dm = g * image[o];
-                    if (g_m) dm += g_m[o];
-                    dz = (dm * (1.0f - m)) * m;
-                    if (center) {
-                        dimage[o] = g * m;
-                        bsum3[co] += dz;
-                    }
+                pre_g[h][co] = in ? g_t[co * plane + o] : 0.0f;
+                pre_i[h][co] = in ? image[co * plane + o] : 0.0f;
+                pre_m[h][co] = in ? mapping[co * plane + o] : 0.0f;
+                pre_gm[h][co] = (in && g_m) ? g_m[co * plane + o] : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](int tile) {
+        const int ty0 = (tile / tiles_x) * TH_SMALL, tx0 = (tile % tiles_x) * TW;
+        tile_commit<TW, 2>(a_lds, a_off, pre_a, TH_SMALL, TW, tid);
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+            const int pos = tid + 256 * h, ry = pos / RS, rx = pos - ry * RS;
+            const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
+            if (pos >= PS_DZ3) continue;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            const bool center = in && ry >= 1 && ry <= TH_SMALL && rx >= 1 && rx <= TW;
+#pragma unroll
+            for (int co = 0; co < AO; co++) {
+                const float g = pre_g[h][co], m = pre_m[h][co];
+                const float dm = g * pre_i[h][co] + pre_gm[h][co];  // outside the image every term is 0
+                const float dz = (dm * (1.0f - m)) * m;
+                if (center) {
+                    dimage[co * plane + (size_t)y * W + x] = g * m;
+                    bsum3[co] += dz;
                 }
                 z_lds[co * PS_DZ3 + pos] = dz;
             }
         }
-        __syncthreads();
+    };
+    if ((int)blockIdx.x < n_tiles) {
+        fetch(blockIdx.x);
+        commit(blockIdx.x);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int ty0 = (tile / tiles_x) * TH_SMALL, tx0 = (tile % tiles_x) * TW;
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) fetch(next);
         // operands of one 16-pixel segment (19 LDS reads + 4 mask reads) are fetched one segment ahead of its 15 MFMAs
         auto load_seg = [&](float(&zd)[7], float(&av)[4], float(&zw)[8], float(&am)[4], int seg) {
             const int r = wave * 2 + (seg >> 2), x0 = (seg & 3) * 16;
@@ -384,6 +544,9 @@ __global__ __launch_bounds__(256) void app_conv3_bwd_kernel(int H, int W, int ti
                 if (y < H && x < W) dz2[(4 * k + reg) * plane + (size_t)y * W + x] = v;
             }
         }
+        __syncthreads();  // every wave is done reading this tile
+        if (next < n_tiles) commit(next);
+        __syncthreads();
     }
     // workgroup totals: dW3 D layout = row ci = 4k + reg, column col = 16 nb + n
     float* redW = red;             // [wave][nb][reg][lane]
@@ -420,27 +583,41 @@ __global__ __launch_bounds__(256) void app_conv3_bwd_kernel(int H, int W, int ti
 
 // ------------------------------------------------------------------------------------------------------------------
 // dW2[co][ci][tap] += sum_q dz2[co][q] u[ci][q + tap]: A[co = n][q = k], B[q = k][ci = n] per tap, 9 MFMAs per 4 pixels,
-// u rebuilt from feat per 8 x 64 tile.  One row of 2304 partial sums per workgroup (layout [tap][co][ci]).
+// u as the forward saved it.  One row of 2304 partial sums per workgroup (layout [tap][co][ci]).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int B3_PARTIAL = 9 * AC * AC;
 
-__global__ __launch_bounds__(256) void app_conv2_bwd_weight_kernel(int H, int W, int Hh, int Wh, float sy, float sx, int tiles_x,
-                                                                   int n_tiles, const float* __restrict__ feat,
+__global__ __launch_bounds__(256) void app_conv2_bwd_weight_kernel(int H, int W, int tiles_x, int n_tiles, const float* __restrict__ u,
                                                                    const float* __restrict__ dz2, float* __restrict__ partials)
 {
     __shared__ float d_lds[AC * PS_CENTER];
     __shared__ float u_lds[AC * PS_HALO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, k = lane >> 4;
     const int d_base = plane_base(n, PS_CENTER) + k, u_base = plane_base(n, PS_HALO) + k;
+    auto d_off = [](int c) { return plane_base(c, PS_CENTER); };
+    auto u_off = [](int c) { return plane_base(c, PS_HALO); };
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // the next tile (dz2 centre, u with halo) travels in registers while this one's 288 MFMAs per wave run
+    float pre_d[2][AC], pre_u[3][AC];
+    auto fetch = [&](int tile) {
         const int ty0 = (tile / tiles_x) * TH_SMALL, tx0 = (tile % tiles_x) * TW;
-        __syncthreads();
-        fill_tile<TW>(d_lds, [](int c) { return plane_base(c, PS_CENTER); }, TH_SMALL, TW, ty0, tx0, H, W, dz2, tid);
-        fill_upsampled_tile(u_lds, [](int c) { return plane_base(c, PS_HALO); }, TH_SMALL, ty0, tx0, H, W, Hh, Wh, sy, sx, feat, tid);
-        __syncthreads();
+        tile_fetch<TW, 2>(pre_d, TH_SMALL, ty0, tx0, H, W, dz2, tid);
+        tile_fetch<RS, 3>(pre_u, TH_SMALL + 2, ty0 - 1, tx0 - 1, H, W, u, tid);
+    };
+    auto commit = [&]() {
+        tile_commit<TW, 2>(d_lds, d_off, pre_d, TH_SMALL, TW, tid);
+        tile_commit<RS, 3>(u_lds, u_off, pre_u, TH_SMALL + 2, RS, tid);
+    };
+    if ((int)blockIdx.x < n_tiles) {
+        fetch(blockIdx.x);
+        commit();
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) fetch(next);
         // the 10 operands of one 4-pixel step are fetched one step ahead of its 9 MFMAs
         auto load_step = [&](float& a_op, float(&b_op)[9], int step) {
             const int r = wave * 2 + (step >> 4), x0 = (step & 15) * 4;
@@ -463,8 +640,10 @@ __global__ __launch_bounds__(256) void app_conv2_bwd_weight_kernel(int H, int W,
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();  // every wave is done reading this tile
+        if (next < n_tiles) commit();
+        __syncthreads();
     }
-    __syncthreads();
     float* red = u_lds;  // [wave][t][reg][lane] = 4 x 2304 floats <= AC * PS_HALO
 #pragma unroll
     for (int t = 0; t < 9; t++)
@@ -548,7 +727,7 @@ __global__ __launch_bounds__(256) void app_upsample_bwd_kernel(int H, int W, int
 // The same adjoint for the scales the network produces (about 1/2): one workgroup per 8 x 32 tile of feat.  The output-space
 // region that can touch the tile is staged in LDS once per channel and reduced separably, first along x with the tile
 // columns' weights, then along y -- each du element is read once (plus the region overlap) instead of ~6 times.
-constexpr int UB_HT = 8, UB_WT = 32, UB_ROWS = 26, UB_COLS = 80, UB_TAPS = 8;
+constexpr int UB_HT = 8, UB_WT = 32, UB_ROWS = 26, UB_COLS = 80, UB_TAPS = 5;
 inline bool upsample_bwd_tiled_ok(float sy, float sx) { return sy >= 0.41f && sx >= 0.435f; }  // regions and windows fit
 
 __global__ __launch_bounds__(256) void app_upsample_bwd_tiled_kernel(int H, int W, int Hh, int Wh, float sy, float sx,
@@ -562,14 +741,23 @@ __global__ __launch_bounds__(256) void app_upsample_bwd_tiled_kernel(int H, int 
     // first output pixel that can have source index >= h - 1 (two pixels of slack for the float division)
     auto first_dst = [](int h, float s) { return max(0, (int)floorf((float)(h - 1) / s) - 1); };
     const int y_lo = first_dst(hy0, sy), x_lo = first_dst(hx0, sx);
-    const int xw = first_dst(hx, sx) - x_lo, yw = first_dst(hy, sy) - y_lo;  // this thread's tap windows inside the region
+    // this thread's tap windows inside the region: at these scales a source pixel is touched by at most 5 consecutive
+    // destination pixels (2 / s < 5); the window starts on the first of them, found among the first candidates
+    auto weight = [](int dst, int n_dst, int h, int n_in, float s) {
+        const Lerp l = lerp_coord(min(dst, n_dst - 1), n_in, s);
+        return dst < n_dst ? (l.i0 == h ? l.l0 : 0.0f) + (l.i1 == h ? l.l1 : 0.0f) : 0.0f;
+    };
+    int xw = first_dst(hx, sx) - x_lo, yw = first_dst(hy, sy) - y_lo;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if (weight(x_lo + xw, W, hx, Wh, sx) == 0.0f) xw++;
+        if (weight(y_lo + yw, H, hy, Hh, sy) == 0.0f) yw++;
+    }
     float wx[UB_TAPS], wy[UB_TAPS];
 #pragma unroll
     for (int j = 0; j < UB_TAPS; j++) {
-        const int x = x_lo + xw + j, y = y_lo + yw + j;
-        const Lerp lx = lerp_coord(min(x, W - 1), Wh, sx), ly = lerp_coord(min(y, H - 1), Hh, sy);
-        wx[j] = (x < W && xw + j < UB_COLS) ? (lx.i0 == hx ? lx.l0 : 0.0f) + (lx.i1 == hx ? lx.l1 : 0.0f) : 0.0f;
-        wy[j] = (y < H && yw + j < UB_ROWS) ? (ly.i0 == hy ? ly.l0 : 0.0f) + (ly.i1 == hy ? ly.l1 : 0.0f) : 0.0f;
+        wx[j] = xw + j < UB_COLS ? weight(x_lo + xw + j, W, hx, Wh, sx) : 0.0f;
+        wy[j] = yw + j < UB_ROWS ? weight(y_lo + yw + j, H, hy, Hh, sy) : 0.0f;
     }
     const size_t plane = (size_t)H * W, hplane = (size_t)Hh * Wh;
     constexpr int PER_THREAD = (UB_ROWS * UB_COLS + 255) / 256;
@@ -610,7 +798,11 @@ __global__ __launch_bounds__(256) void app_upsample_bwd_tiled_kernel(int H, int 
 inline float up_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int MAX_PARTIAL_ROWS = 1024;
-constexpr int CONV16_GRID = 512;  // 2 workgroups (76.8 KB of LDS each) per CU x 256 CUs
+constexpr int CONV3_BWD_GRID = 512;    // 2 workgroups (55 KB of LDS each, ~200 VGPRs) per CU
+constexpr int CONV3_FWD_GRID = 512;    // 2 workgroups (79 KB of LDS each) per CU
+constexpr int WGRAD_GRID = 512;        // 2 workgroups (80 KB of LDS each) per CU
+constexpr int CONV16_FWD_GRID = 512;  // 2 workgroups (62 KB of LDS each) per CU x 256 CUs
+constexpr int CONV16_BWD_GRID = 512;  // 2 per CU (188 VGPRs; forcing 3 waves per SIMD spills and measured slower)
 
 }  // namespace
 
@@ -628,9 +820,12 @@ size_t gsr_appearance_layout(int H, int W, size_t* dz2_off, size_t* du_off, size
 void gsr_launch_appearance_forward(int H, int W, int Hh, int Wh, const float* feat, const float* w2, const float* b2, const float* w3,
                                    const float* b3, const float* image, float* mapping, float* transformed, float* saved_a, hipStream_t s)
 {
-    const int tx = cdiv(W, TW), tiles = tx * cdiv(H, TH_BIG);
-    app_conv16_kernel<false><<<tiles < CONV16_GRID ? tiles : CONV16_GRID, 256, 0, s>>>(H, W, Hh, Wh, up_scale(Hh, H), up_scale(Wh, W), tx, tiles, feat, w2, b2, saved_a, getenv("GSR_APP_DBG") ? atoi(getenv("GSR_APP_DBG")) : 0);
-    app_conv3_fwd_kernel<<<tiles, 256, 0, s>>>(H, W, tx, saved_a, w3, b3, image, mapping, transformed);
+    const int tx = cdiv(W, TW), tiles = tx * cdiv(H, TH_BIG), tiles8 = tx * cdiv(H, TH_SMALL);
+    const float sy = up_scale(Hh, H), sx = up_scale(Wh, W);
+    float* saved_u = saved_a + (size_t)AC * H * W;
+    app_conv16_kernel<false><<<tiles8 < CONV16_FWD_GRID ? tiles8 : CONV16_FWD_GRID, 256, 0, s>>>(
+        H, W, Hh, Wh, sy, sx, tx, tiles8, upsample_staged_ok(sy, sx) ? 1 : 0, feat, w2, b2, saved_a, saved_u);
+    app_conv3_fwd_kernel<<<tiles < CONV3_FWD_GRID ? tiles : CONV3_FWD_GRID, 256, 0, s>>>(H, W, tx, tiles, saved_a, w3, b3, image, mapping, transformed);
 }
 
 void gsr_launch_appearance_backward(int H, int W, int Hh, int Wh, const float* feat, const float* w2, const float* w3, const float* image,
@@ -645,12 +840,15 @@ void gsr_launch_appearance_backward(int H, int W, int Hh, int Wh, const float* f
     float* p3 = (float*)(scratch + o_p3);
     float* p2 = (float*)(scratch + o_p2);
     const float sy = up_scale(Hh, H), sx = up_scale(Wh, W);
-    const int tx = cdiv(W, TW), tiles_small = tx * cdiv(H, TH_SMALL), tiles_big = tx * cdiv(H, TH_BIG);
-    const int rows = tiles_small < MAX_PARTIAL_ROWS ? tiles_small : MAX_PARTIAL_ROWS;
+    const int tx = cdiv(W, TW), tiles_small = tx * cdiv(H, TH_SMALL);
+    const int rows = tiles_small < CONV3_BWD_GRID ? tiles_small : CONV3_BWD_GRID;
+    const int rows2 = tiles_small < WGRAD_GRID ? tiles_small : WGRAD_GRID;
+    const float* saved_u = saved_a + (size_t)AC * H * W;
     app_conv3_bwd_kernel<<<rows, 256, 0, s>>>(H, W, tx, tiles_small, saved_a, w3, image, mapping, g_transformed, g_mapping, dimage, dz2, p3);
-    app_conv2_bwd_weight_kernel<<<rows, 256, 0, s>>>(H, W, Hh, Wh, sy, sx, tx, tiles_small, feat, dz2, p2);
-    app_conv16_kernel<true><<<tiles_big < CONV16_GRID ? tiles_big : CONV16_GRID, 256, 0, s>>>(H, W, Hh, Wh, sy, sx, tx, tiles_big, dz2, w2, nullptr, du, getenv("GSR_APP_DBG") ? atoi(getenv("GSR_APP_DBG")) : 0);
-    app_reduce_partials_kernel<<<cdiv(27 * AC + AO + AC + B3_PARTIAL, 4), 256, 0, s>>>(p3, rows, p2, rows, dw3, db3, db2, dw2);
+    app_conv2_bwd_weight_kernel<<<rows2, 256, 0, s>>>(H, W, tx, tiles_small, saved_u, dz2, p2);
+    app_conv16_kernel<true><<<tiles_small < CONV16_BWD_GRID ? tiles_small : CONV16_BWD_GRID, 256, 0, s>>>(H, W, Hh, Wh, sy, sx, tx, tiles_small, 0,
+                                                                                                 dz2, w2, nullptr, du, nullptr);
+    app_reduce_partials_kernel<<<cdiv(27 * AC + AO + AC + B3_PARTIAL, 4), 256, 0, s>>>(p3, rows, p2, rows2, dw3, db3, db2, dw2);
     if (upsample_bwd_tiled_ok(sy, sx))
         app_upsample_bwd_tiled_kernel<<<dim3(cdiv(Wh, UB_WT), cdiv(Hh, UB_HT)), 256, 0, s>>>(H, W, Hh, Wh, sy, sx, du, dfeat);
     else

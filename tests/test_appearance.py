@@ -55,7 +55,7 @@ def _run_hip(feat, w2, b2, w3, b3, image, r1, r2):
     if r2 is not None:
         loss = loss + (mapping * torch.tensor(r2, device="cuda")).sum()
     H, W = image.shape[1:]
-    saved_a = transformed.grad_fn.saved_tensors[5].view(torch.float32).view(16, H, W).cpu().numpy()  # relu(conv2) as the kernels kept it
+    saved_a = transformed.grad_fn.saved_tensors[5].view(torch.float32)[:16 * H * W].view(16, H, W).cpu().numpy()  # relu(conv2) as the kernels kept it
     loss.backward()
     names = ("feat", "w2", "b2", "w3", "b3", "image")
     grads = {n: v.grad.cpu().numpy() for n, v in zip(names, ins)}

@@ -1,0 +1,17 @@
+"""Runs the HIP appearance tail (forward + backward) N times at 1080p: the driver behind profiles/r01_appearance_*.  Usage, on
+the GPU box: rocprofv3 --kernel-trace --stats --output-format csv -d out -o app -- python3 tools/appearance_tail_driver.py 10"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from based_on_point_cloud_partitions_amd.appearance import appearance_tail
+H, W = 1080, 1920
+torch.manual_seed(0)
+feat = torch.rand(16, 528, 960, device="cuda", requires_grad=True)
+w2 = (0.2 * torch.randn(16, 16, 3, 3, device="cuda")).requires_grad_(True); b2 = torch.zeros(16, device="cuda", requires_grad=True)
+w3 = (0.2 * torch.randn(3, 16, 3, 3, device="cuda")).requires_grad_(True); b3 = torch.zeros(3, device="cuda", requires_grad=True)
+img = torch.rand(3, H, W, device="cuda")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+for _ in range(n):
+    t, m = appearance_tail(feat, w2, b2, w3, b3, img)
+    t.sum().backward()
+torch.cuda.synchronize()

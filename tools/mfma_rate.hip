@@ -44,6 +44,57 @@ __global__ void __launch_bounds__(256) k32(float* out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the issue pattern of app_conv16_kernel: per tap 16 MFMAs (4 accumulators x 4 weight registers), the next tap's 16 B
+// operands read from LDS meanwhile.  MODE 0: as in the kernel; 1: no sched_group_barrier; 2: B operands reused (one LDS
+// read per tap only); 3: ds_read_b64 pairs
+template <int MODE>
+__global__ void __launch_bounds__(256) kconv(float* out, int iters)
+{
+    __shared__ float lds[16 * 688];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, k = lane >> 4;
+    for (int i = tid; i < 16 * 688; i += 256) lds[i] = 0.001f * i;
+    __syncthreads();
+    float wreg[36];
+    for (int i = 0; i < 36; i++) wreg[i] = 0.01f * (i + lane);
+    const float* bbase = lds + k * 688 + n;
+    f32x4 acc[4];
+    for (int i = 0; i < 4; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bq[2][16];
+    auto load_tap = [&](float(&b)[16], int row, int t) {
+        const int dy = t / 3, dx = t % 3;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) b[j * 4 + s] = bbase[4 * j * 688 + (row + dy) * 66 + s * 16 + dx];
+    };
+    for (int it = 0; it < iters; it++) {
+        load_tap(bq[0], it & 7, 0);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            if (t + 1 < 9) {
+                if (MODE == 2) bq[(t + 1) & 1][0] = bbase[(it & 7) * 66 + t];
+                else load_tap(bq[(t + 1) & 1], it & 7, t + 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t * 4 + j], bq[t & 1][MODE == 2 ? 0 : j * 4 + s], acc[s], 0, 0, 0);
+            if (MODE != 1) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename K>
 static void run(const char* name, K kern, int nacc, int flop_per, int waves_per_simd, float* out)
 {
@@ -77,6 +128,11 @@ int main()
         run("32x32x2", k32<1>, 1, 4096, w, out);
         run("32x32x2", k32<2>, 2, 4096, w, out);
         run("32x32x2", k32<4>, 4, 4096, w, out);
+    }
+    for (int w = 1; w <= 2; w++) {
+        run("conv m0", kconv<0>, 9, 2048, w, out);  // 144 MFMAs per iteration = 16 x 9
+        run("conv m1", kconv<1>, 9, 2048, w, out);
+        run("conv m2", kconv<2>, 9, 2048, w, out);
     }
     // long run: does the rate hold for ~100 ms?
     for (int rep = 0; rep < 3; rep++) run("16x16x4", k16<4>, 4, 2048, 2, out);
