@@ -95,6 +95,63 @@ __global__ void __launch_bounds__(256) kconv(float* out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// MFMAs with independent streaming traffic beside them, in the proportion of the data-gradient conv kernel: per 144 MFMAs a
+// wave loads 24 x 256 B and stores 16 x 256 B.  MODE 0: both; 1: MFMAs only; 2: traffic only.  Do they overlap?
+template <int MODE>
+__global__ void __launch_bounds__(256) kmix(float* out, const float* __restrict__ src, float* __restrict__ dst, int iters)
+{
+    f32x4 acc[4];
+    for (int i = 0; i < 4; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a = threadIdx.x * 0.001f, b = 1.0f + threadIdx.x * 0.002f;
+    const size_t wave_id = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float carry = 0.f;
+    for (int it = 0; it < iters; it++) {
+        float v[24];
+        if (MODE != 1) {
+            const float* p = src + ((wave_id * iters + it) * 24) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 24; i++) v[i] = p[i * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep [loads][MFMAs][stores]: the compiler otherwise pulls the stores (and the wait) up
+        if (MODE != 2) {
+#pragma unroll
+            for (int r = 0; r < 36; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE != 1) {
+            float* q = dst + ((wave_id * iters + it) * 16) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 16; i++) q[i * 64] = v[i] + v[(i + 8) % 24] + carry;
+            carry = v[23];
+        }
+    }
+    float s = carry;
+    for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE>
+static void run_mix(float* out, const float* src, float* dst)
+{
+    const int iters = 60, blocks = 512;  // 2 waves per SIMD, ~8 "tiles" of 288 MFMAs x 2 per wave
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    kmix<MODE><<<blocks, 256>>>(out, src, dst, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kmix<MODE><<<blocks, 256>>>(out, src, dst, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)blocks * 4 * iters * (24 + 16) * 256;
+    printf("mix mode %d: %.3f ms  (%.1f MB moved -> %.2f TB/s;  %.1f cycles per MFMA per SIMD at 2.4 GHz)\n", MODE, ms, bytes / 1e6,
+           MODE == 1 ? 0.0 : bytes / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (iters * 144.0 * 2));
+}
+
 template <typename K>
 static void run(const char* name, K kern, int nacc, int flop_per, int waves_per_simd, float* out)
 {
@@ -133,6 +190,17 @@ int main()
         run("conv m0", kconv<0>, 9, 2048, w, out);  // 144 MFMAs per iteration = 16 x 9
         run("conv m1", kconv<1>, 9, 2048, w, out);
         run("conv m2", kconv<2>, 9, 2048, w, out);
+    }
+    {
+        float *src, *dst;
+        const size_t n_src = (size_t)512 * 4 * 60 * 24 * 64, n_dst = (size_t)512 * 4 * 60 * 16 * 64;
+        hipMalloc(&src, n_src * sizeof(float));
+        hipMalloc(&dst, n_dst * sizeof(float));
+        hipMemset(src, 0, n_src * sizeof(float));
+        run_mix<1>(out, src, dst);
+        run_mix<2>(out, src, dst);
+        run_mix<0>(out, src, dst);
+        run_mix<0>(out, src, dst);
     }
     // long run: does the rate hold for ~100 ms?
     for (int rep = 0; rep < 3; rep++) run("16x16x4", k16<4>, 4, 2048, 2, out);
