@@ -3,7 +3,8 @@
 // backward.  As stock torch ops this tail is 2.6 ms of the 3.7 ms the network costs per training iteration at 1080p
 // (tools/appearance_probe.py) -- three times the rasterizer step.
 //
-//   u  = bilinear(feat [16,h,w] -> [16,H,W], align_corners)         never materialised: rebuilt per tile in LDS
+//   u  = bilinear(feat [16,h,w] -> [16,H,W], align_corners)         built per tile in LDS from the patch of feat under it;
+//                                                                   also written out once: the weight gradient reads it
 //   a  = relu(conv3x3(u, w2) + b2)          [16,H,W]               saved for backward
 //   m  = sigmoid(conv3x3(a, w3) + b3)       [3,H,W]                mapping_image
 //   t  = m * image                                                  transformed_image
@@ -24,7 +25,7 @@ constexpr int TW = 64;  // tile width of every kernel here
 constexpr int RS = TW + 2;  // LDS row stride of a tile with a one-pixel halo
 
 // Tiles with a halo, read as MFMA B operands "4 channel planes x 16 consecutive pixels" (ds_read_b32 serves lanes 0-31 and
-// 32-63 separately, bank = dword address mod 32): planes 16 banks apart.
+// 32-63 separately, bank = dword address mod 32): planes 16 banks apart (PS8 below; PS_BIG for the 16-row tile of conv3 forward).
 constexpr int TH_BIG = 16;
 constexpr int PS_BIG = 1200;  // >= (TH_BIG + 2) * RS = 1188, = 16 mod 32
 // Tiles read as "16 channel planes x 2 consecutive pixels" per half-wave (the reduction index is the pixel): plane i starts
@@ -80,40 +81,6 @@ __device__ __forceinline__ void fill_upsampled_tile(float* lds, PlaneOff plane_o
             if (center) u_out[c * oplane + (size_t)y * W + x] = u;
             p += plane;
         }
-    }
-}
-
-// 16-plane tile of `rows` x WIDTH pixels whose first pixel is (y_first, x_first), LDS row stride `row_stride`, from a CHW
-// tensor; zero outside the image.  Each thread takes two positions per round and issues their 32 loads before the first
-// LDS store, so a tile costs two or three memory round trips instead of one per element.
-template <int WIDTH, typename PlaneOff>
-__device__ __forceinline__ void fill_tile(float* lds, PlaneOff plane_off, int rows, int row_stride, int y_first, int x_first, int H, int W,
-                                          const float* __restrict__ src, int tid)
-{
-    const int n = rows * WIDTH;
-    const size_t plane = (size_t)H * W;
-    for (int pos0 = tid; pos0 < n; pos0 += 512) {
-        float v[2][AC];
-        int dst[2];
-        bool live[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int pos = pos0 + 256 * h;
-            const int ry = pos / WIDTH, rx = pos - ry * WIDTH;
-            const int y = y_first + ry, x = x_first + rx;
-            live[h] = pos < n;
-            const bool in = live[h] && y >= 0 && y < H && x >= 0 && x < W;
-            dst[h] = ry * row_stride + rx;
-            const float* p = src + (size_t)(in ? y : 0) * W + (in ? x : 0);
-#pragma unroll
-            for (int c = 0; c < AC; c++) v[h][c] = in ? p[c * plane] : 0.0f;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-            if (live[h]) {
-#pragma unroll
-                for (int c = 0; c < AC; c++) lds[plane_off(c) + dst[h]] = v[h][c];
-            }
     }
 }
 
