@@ -3,9 +3,11 @@
 `decouple_appearance(image, gaussians, view_idx)` has the name, arguments and results of scene/ptgs/appearance_network.py:7-17
 (train.py:110-111).  The network is the caller's own `gaussians.appearance_network` (the reference's AppearanceNetwork, used as
 is: its parameters are read, never copied).  Its low-resolution head -- conv1 and the four pixel-shuffle blocks, at most a
-quarter of the image's pixels -- runs as the module's own layers; everything from the bilinear upsampling to full resolution
-on (:54-60) and the final `mapping_image * image` (:15) is one HIP forward and one HIP backward (csrc/appearance.hip): as stock
-torch ops that tail is 2.6 of the network's 3.7 ms per iteration at 1080p.  HIP only: a CPU tensor or a missing library raises.
+quarter of the image's pixels -- runs as the module's own layers, except the last block `up4` (PixelShuffle + conv 8->16 + ReLU
+at half the image's resolution, a third of the head's time), which is HIP too when it has the reference's shape; everything from
+the bilinear upsampling to full resolution on (:54-60) and the final `mapping_image * image` (:15) is one HIP forward and one HIP
+backward (csrc/appearance.hip): as stock torch ops that tail is 2.6 of the network's 3.7 ms per iteration at 1080p.  HIP only: a
+CPU tensor or a missing library raises.
 """
 import ctypes
 
@@ -19,6 +21,14 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _check_tail_shapes(feat, w2, b2, w3, b3, image):
+    if feat.dim() != 3 or feat.shape[0] != 16 or tuple(w2.shape) != (16, 16, 3, 3) or tuple(b2.shape) != (16,) or \
+            tuple(w3.shape) != (3, 16, 3, 3) or tuple(b3.shape) != (3,) or image.dim() != 3 or image.shape[0] != 3:
+        raise _lib.GsrError("appearance tail: expected feat [16,h,w], conv2 16->16 3x3, conv3 16->3 3x3 and an image [3,H,W] "
+                            f"(appearance_network.py:47-48), got {tuple(feat.shape)}, {tuple(w2.shape)}, {tuple(w3.shape)}, "
+                            f"{tuple(image.shape)}")
+
+
 class _AppearanceTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, w2, b2, w3, b3, image):
@@ -27,46 +37,96 @@ class _AppearanceTail(torch.autograd.Function):
                 raise _lib.GsrError("appearance tail inputs must live on a HIP device; there is no CPU fallback")
             if t.dtype != torch.float32:
                 raise _lib.GsrError("appearance tail inputs must be float32")
-        if feat.dim() != 3 or feat.shape[0] != 16 or tuple(w2.shape) != (16, 16, 3, 3) or tuple(b2.shape) != (16,) or \
-                tuple(w3.shape) != (3, 16, 3, 3) or tuple(b3.shape) != (3,) or image.dim() != 3 or image.shape[0] != 3:
-            raise _lib.GsrError("appearance tail: expected feat [16,h,w], conv2 16->16 3x3, conv3 16->3 3x3 and an image [3,H,W] "
-                                f"(appearance_network.py:47-48), got {tuple(feat.shape)}, {tuple(w2.shape)}, {tuple(w3.shape)}, "
-                                f"{tuple(image.shape)}")
+        _check_tail_shapes(feat, w2, b2, w3, b3, image)
         lib = _lib.load()
-        dev = image.device
         feat, w2, b2, w3, b3, image = (t.contiguous() for t in (feat, w2, b2, w3, b3, image))
-        H, W = image.shape[1:]
         ctx.set_materialize_grads(False)
-        with torch.cuda.device(dev):
-            saved = torch.empty(lib.gsr_appearance_saved_bytes(H, W), dtype=torch.uint8, device=dev)
-            mapping, transformed = torch.empty_like(image), torch.empty_like(image)
-            s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.gsr_appearance_tail_forward(H, W, feat.shape[1], feat.shape[2], _p(feat), _p(w2), _p(b2), _p(w3), _p(b3),
-                                                       _p(image), _p(mapping), _p(transformed), _p(saved), saved.numel(), s),
-                       "gsr_appearance_tail_forward")
+        with torch.cuda.device(image.device):
+            transformed, mapping, saved = _tail_forward(lib, feat, w2, b2, w3, b3, image)
         ctx.save_for_backward(feat, w2, w3, image, mapping, saved)
         return transformed, mapping
 
     @staticmethod
     def backward(ctx, g_transformed, g_mapping):
         feat, w2, w3, image, mapping, saved = ctx.saved_tensors
+        with torch.cuda.device(image.device):
+            return _tail_backward(_lib.load(), feat, w2, w3, image, mapping, saved, g_transformed, g_mapping, False)
+
+
+def _tail_forward(lib, feat, w2, b2, w3, b3, image):
+    dev = image.device
+    H, W = image.shape[1:]
+    saved = torch.empty(lib.gsr_appearance_saved_bytes(H, W), dtype=torch.uint8, device=dev)
+    mapping, transformed = torch.empty_like(image), torch.empty_like(image)
+    s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.gsr_appearance_tail_forward(H, W, feat.shape[1], feat.shape[2], _p(feat), _p(w2), _p(b2), _p(w3), _p(b3), _p(image),
+                                               _p(mapping), _p(transformed), _p(saved), saved.numel(), s), "gsr_appearance_tail_forward")
+    return transformed, mapping, saved
+
+
+def _tail_backward(lib, feat, w2, w3, image, mapping, saved, g_transformed, g_mapping, mask_relu):
+    dev = image.device
+    H, W = image.shape[1:]
+    g_t = g_transformed.to(torch.float32).contiguous() if g_transformed is not None else torch.zeros_like(image)
+    g_m = g_mapping.to(torch.float32).contiguous() if g_mapping is not None else None
+    d_image, d_feat = torch.empty_like(image), torch.empty_like(feat)
+    d_w2, d_w3 = torch.empty_like(w2), torch.empty_like(w3)
+    d_b2 = torch.empty(16, dtype=torch.float32, device=dev)
+    d_b3 = torch.empty(3, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.gsr_appearance_scratch_bytes(H, W), dtype=torch.uint8, device=dev)
+    s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.gsr_appearance_tail_backward(H, W, feat.shape[1], feat.shape[2], _p(feat), _p(w2), _p(w3), _p(image), _p(mapping),
+                                                _p(saved), saved.numel(), _p(g_t), _p(g_m), _p(d_image), _p(d_feat), _p(d_w2),
+                                                _p(d_b2), _p(d_w3), _p(d_b3), _p(scratch), scratch.numel(), int(mask_relu), s),
+               "gsr_appearance_tail_backward")
+    return d_feat, d_w2, d_b2, d_w3, d_b3, d_image
+
+
+class _AppearanceUpTail(torch.autograd.Function):
+    """`up4` (PixelShuffle(2) -> Conv2d(8, 16, 3, padding=1) -> ReLU) and the tail in one node: the ReLU's mask is applied where the
+    tail's backward writes dL/dfeat, and feat never passes through torch."""
+
+    @staticmethod
+    def forward(ctx, x, w4, b4, w2, b2, w3, b3, image):
+        for t in (x, w4, b4, w2, b2, w3, b3, image):
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise _lib.GsrError("appearance inputs must be float32 tensors on a HIP device; there is no CPU fallback")
         lib = _lib.load()
         dev = image.device
-        H, W = image.shape[1:]
-        g_t = g_transformed.to(torch.float32).contiguous() if g_transformed is not None else torch.zeros_like(image)
-        g_m = g_mapping.to(torch.float32).contiguous() if g_mapping is not None else None
+        x, w4, b4, w2, b2, w3, b3, image = (t.contiguous() for t in (x, w4, b4, w2, b2, w3, b3, image))
+        fh, fw = 2 * x.shape[1], 2 * x.shape[2]
+        ctx.set_materialize_grads(False)
         with torch.cuda.device(dev):
-            d_image, d_feat = torch.empty_like(image), torch.empty_like(feat)
-            d_w2, d_w3 = torch.empty_like(w2), torch.empty_like(w3)
-            d_b2 = torch.empty(16, dtype=torch.float32, device=dev)
-            d_b3 = torch.empty(3, dtype=torch.float32, device=dev)
-            scratch = torch.empty(lib.gsr_appearance_scratch_bytes(H, W), dtype=torch.uint8, device=dev)
+            feat = torch.empty(16, fh, fw, dtype=torch.float32, device=dev)
             s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.gsr_appearance_tail_backward(H, W, feat.shape[1], feat.shape[2], _p(feat), _p(w2), _p(w3), _p(image), _p(mapping),
-                                                        _p(saved), saved.numel(), _p(g_t), _p(g_m), _p(d_image), _p(d_feat), _p(d_w2),
-                                                        _p(d_b2), _p(d_w3), _p(d_b3), _p(scratch), scratch.numel(), s),
-                       "gsr_appearance_tail_backward")
-        return d_feat, d_w2, d_b2, d_w3, d_b3, d_image
+            _lib.check(lib.gsr_appearance_up_forward(fh, fw, _p(x), _p(w4), _p(b4), _p(feat), s), "gsr_appearance_up_forward")
+            transformed, mapping, saved = _tail_forward(lib, feat, w2, b2, w3, b3, image)
+        ctx.save_for_backward(x, w4, feat, w2, w3, image, mapping, saved)
+        return transformed, mapping
+
+    @staticmethod
+    def backward(ctx, g_transformed, g_mapping):
+        x, w4, feat, w2, w3, image, mapping, saved = ctx.saved_tensors
+        lib = _lib.load()
+        dev = image.device
+        with torch.cuda.device(dev):
+            dz, d_w2, d_b2, d_w3, d_b3, d_image = _tail_backward(lib, feat, w2, w3, image, mapping, saved, g_transformed, g_mapping, True)
+            d_x, d_w4 = torch.empty_like(x), torch.empty_like(w4)
+            d_b4 = torch.empty(16, dtype=torch.float32, device=dev)
+            fh, fw = feat.shape[1:]
+            scratch = torch.empty(lib.gsr_appearance_up_scratch_bytes(fh, fw), dtype=torch.uint8, device=dev)
+            s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.gsr_appearance_up_backward(fh, fw, _p(x), _p(w4), _p(dz), _p(d_x), _p(d_w4), _p(d_b4), _p(scratch),
+                                                      scratch.numel(), s), "gsr_appearance_up_backward")
+        return d_x, d_w4, d_b4, d_w2, d_b2, d_w3, d_b3, d_image
+
+
+def appearance_up_tail(x, up_weight, up_bias, conv2_weight, conv2_bias, conv3_weight, conv3_bias, image):
+    """(transformed_image, mapping_image) from `up3`'s output [32,h,w] (appearance_network.py:51) and the rendered image: `up4` + tail."""
+    if x.dim() != 3 or x.shape[0] != 32 or tuple(up_weight.shape) != (16, 8, 3, 3) or tuple(up_bias.shape) != (16,):
+        raise _lib.GsrError(f"appearance up block: expected x [32,h,w] and Conv2d(8, 16, 3), got {tuple(x.shape)}, {tuple(up_weight.shape)}")
+    _check_tail_shapes(x.new_empty(16, 1, 1), conv2_weight, conv2_bias, conv3_weight, conv3_bias, image)
+    return _AppearanceUpTail.apply(x, up_weight, up_bias, conv2_weight, conv2_bias, conv3_weight, conv3_bias, image)
 
 
 def appearance_tail(feat, conv2_weight, conv2_bias, conv3_weight, conv3_bias, image):
@@ -82,5 +142,10 @@ def decouple_appearance(image, gaussians, view_idx):
     crop_image_down = F.interpolate(image[None], size=(h, w), mode="bilinear", align_corners=True)[0]
     x = torch.cat([crop_image_down, appearance_embedding[None].repeat(h, w, 1).permute(2, 0, 1)], dim=0)[None]
     net = gaussians.appearance_network
-    feat = net.up4(net.up3(net.up2(net.up1(net.relu(net.conv1(x))))))  # appearance_network.py:47-52, the module's own layers
-    return appearance_tail(feat[0], net.conv2.weight, net.conv2.bias, net.conv3.weight, net.conv3.bias, image)
+    x = net.up3(net.up2(net.up1(net.relu(net.conv1(x)))))  # appearance_network.py:47-51, the module's own layers
+    up4_conv = getattr(net.up4, "conv", None)
+    if up4_conv is not None and tuple(up4_conv.weight.shape) == (16, 8, 3, 3) and up4_conv.bias is not None and x.shape[1] == 32 and \
+            getattr(getattr(net.up4, "pixel_shuffle", None), "upscale_factor", None) == 2:
+        return appearance_up_tail(x[0], up4_conv.weight, up4_conv.bias, net.conv2.weight, net.conv2.bias, net.conv3.weight, net.conv3.bias,
+                                  image)
+    return appearance_tail(net.up4(x)[0], net.conv2.weight, net.conv2.bias, net.conv3.weight, net.conv3.bias, image)

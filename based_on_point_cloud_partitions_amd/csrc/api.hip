@@ -553,7 +553,7 @@ int gsr_appearance_tail_backward(int H, int W, int feat_h, int feat_w, const flo
                                  const float* conv3_weight, const float* image, const float* mapping, const void* saved,
                                  size_t saved_bytes, const float* dL_dtransformed, const float* dL_dmapping, float* dL_dimage,
                                  float* dL_dfeat, float* dL_dconv2_weight, float* dL_dconv2_bias, float* dL_dconv3_weight,
-                                 float* dL_dconv3_bias, void* scratch, size_t scratch_bytes, void* stream)
+                                 float* dL_dconv3_bias, void* scratch, size_t scratch_bytes, int mask_relu_of_feat, void* stream)
 {
     if (H <= 0 || W <= 0 || feat_h <= 0 || feat_w <= 0) return fail(-1, "invalid image / feature size");
     if (!feat || !conv2_weight || !conv3_weight || !image || !mapping || !saved || !dL_dtransformed || !dL_dimage || !dL_dfeat ||
@@ -563,8 +563,28 @@ int gsr_appearance_tail_backward(int H, int W, int feat_h, int feat_w, const flo
     if (scratch_bytes < gsr_appearance_scratch_bytes(H, W)) return fail(-3, "appearance scratch too small");
     gsr_launch_appearance_backward(H, W, feat_h, feat_w, feat, conv2_weight, conv3_weight, image, mapping, (const float*)saved,
                                    dL_dtransformed, dL_dmapping, dL_dimage, dL_dfeat, dL_dconv2_weight, dL_dconv2_bias,
-                                   dL_dconv3_weight, dL_dconv3_bias, (char*)scratch, (hipStream_t)stream);
+                                   dL_dconv3_weight, dL_dconv3_bias, (char*)scratch, mask_relu_of_feat, (hipStream_t)stream);
     return check_hip("appearance_tail_backward");
+}
+
+size_t gsr_appearance_up_scratch_bytes(int feat_h, int feat_w) { return feat_h > 0 && feat_w > 0 ? gsr_appearance_up_scratch_bytes_impl() : 0; }
+
+int gsr_appearance_up_forward(int feat_h, int feat_w, const float* x, const float* weight, const float* bias, float* feat, void* stream)
+{
+    if (feat_h <= 0 || feat_w <= 0 || (feat_h & 1) || (feat_w & 1)) return fail(-1, "feature size must be positive and even (PixelShuffle(2))");
+    if (!x || !weight || !bias || !feat) return fail(-1, "NULL required pointer");
+    gsr_launch_appearance_up_forward(feat_h, feat_w, x, weight, bias, feat, (hipStream_t)stream);
+    return check_hip("appearance_up_forward");
+}
+
+int gsr_appearance_up_backward(int feat_h, int feat_w, const float* x, const float* weight, const float* dz, float* dL_dx,
+                               float* dL_dweight, float* dL_dbias, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (feat_h <= 0 || feat_w <= 0 || (feat_h & 1) || (feat_w & 1)) return fail(-1, "feature size must be positive and even (PixelShuffle(2))");
+    if (!x || !weight || !dz || !dL_dx || !dL_dweight || !dL_dbias || !scratch) return fail(-1, "NULL required pointer");
+    if (scratch_bytes < gsr_appearance_up_scratch_bytes(feat_h, feat_w)) return fail(-3, "appearance up-block scratch too small");
+    gsr_launch_appearance_up_backward(feat_h, feat_w, x, weight, dz, dL_dx, dL_dweight, dL_dbias, (char*)scratch, (hipStream_t)stream);
+    return check_hip("appearance_up_backward");
 }
 
 int gsr_adam_step(int n_tensors, const gsr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream)

@@ -84,6 +84,13 @@ __device__ __forceinline__ void fill_upsampled_tile(float* lds, PlaneOff plane_o
     }
 }
 
+// PixelShuffle(2) of the block that produces feat (appearance_network.py:20-29): ps[c][Y][X] = x[4c + 2 (Y & 1) + (X & 1)][Y/2][X/2]
+constexpr int UC = 8;  // channels after the shuffle (up4: 32 -> 8 -> conv -> 16)
+__device__ __forceinline__ size_t ps_index(int c, int Y, int X, int Wh, size_t hplane)
+{
+    return (size_t)(4 * c + 2 * (Y & 1) + (X & 1)) * hplane + (size_t)(Y >> 1) * Wh + (X >> 1);
+}
+
 // A tile in flight: the 16 channel values of NPOS positions per thread, loaded from a CHW tensor while the previous tile is
 // being computed on (tile_fetch), stored to LDS once that is done (tile_commit).  Zero outside the image.
 template <int WIDTH, int NPOS>
@@ -130,12 +137,13 @@ constexpr int PS8 = 688;  // >= 10 * 66, = 16 mod 32: planes 16 banks apart for 
 constexpr int ST_ROWS = 8, ST_COLS = 36, ST_POS = ST_ROWS * ST_COLS, ST_PER_THREAD = AC * ST_POS / 256;
 inline bool upsample_staged_ok(float sy, float sx) { return sy <= 0.55f && sx <= 0.51f; }  // 9 sy + 2 <= 8, 65 sx + 2 <= 36
 
-template <bool DATA_GRAD>
+template <int MODE>
 __global__ __launch_bounds__(256) void app_conv16_kernel(int H, int W, int Hh, int Wh, float sy, float sx, int tiles_x, int n_tiles,
                                                          int staged, const float* __restrict__ src, const float* __restrict__ w2,
                                                          const float* __restrict__ b2, float* __restrict__ out,
                                                          float* __restrict__ u_out)
 {
+    constexpr bool DATA_GRAD = MODE != 0, UP = MODE == 2;
     __shared__ float lds[AC * PS8];
     __shared__ float stage[DATA_GRAD ? 1 : AC * ST_POS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, k = lane >> 4;
@@ -147,8 +155,9 @@ __global__ __launch_bounds__(256) void app_conv16_kernel(int H, int W, int Hh, i
     for (int t = 0; t < 9; t++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            wreg[t * 4 + j] = DATA_GRAD ? w2[((4 * j + k) * AC + n) * 9 + t]   // du[ci = n] += w2[co = 4j+k][ci][t] * dz2[co]
-                                        : w2[(n * AC + 4 * j + k) * 9 + t];   // a[co = n]  += w2[co][ci = 4j+k][t] * u[ci]
+            wreg[t * 4 + j] = UP          ? (n < UC ? w2[((4 * j + k) * UC + n) * 9 + t] : 0.0f)  // dps[ci = n < 8] += w4[co][ci][t] * dz[co]
+                              : DATA_GRAD ? w2[((4 * j + k) * AC + n) * 9 + t]   // du[ci = n] += w2[co = 4j+k][ci][t] * dz2[co]
+                                          : w2[(n * AC + 4 * j + k) * 9 + t];   // a[co = n]  += w2[co][ci = 4j+k][t] * u[ci]
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) bias[r] = DATA_GRAD ? 0.0f : b2[4 * k + r];
@@ -216,11 +225,18 @@ __global__ __launch_bounds__(256) void app_conv16_kernel(int H, int W, int Hh, i
     // one 16-pixel segment of finished accumulators -> bias, ReLU (forward), CHW store
     auto store_segment = [&](const f32x4& acc, int y, int x) {
         if (y < H && x < W) {
+            if constexpr (UP) {  // rows 0..7 are the shuffled channels: undo the pixel shuffle (x is [32][H/2][W/2])
+                if (k < 2) {
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                float v = acc[reg] + bias[reg];
-                if (!DATA_GRAD) v = fmaxf(v, 0.0f);
-                out[(4 * k + reg) * plane + (size_t)y * W + x] = v;
+                    for (int reg = 0; reg < 4; reg++) out[ps_index(4 * k + reg, y, x, Wh, hplane)] = acc[reg];
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    float v = acc[reg] + bias[reg];
+                    if (!DATA_GRAD) v = fmaxf(v, 0.0f);
+                    out[(4 * k + reg) * plane + (size_t)y * W + x] = v;
+                }
             }
         }
     };
@@ -553,29 +569,55 @@ __global__ __launch_bounds__(256) void app_conv3_bwd_kernel(int H, int W, int ti
 // u as the forward saved it.  One row of 2304 partial sums per workgroup (layout [tap][co][ci]).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int B3_PARTIAL = 9 * AC * AC;
+constexpr int UP_PARTIAL = B3_PARTIAL + AC;  // + the bias gradient
 
+template <bool UP>  // UP: the same for up4's conv (8 shuffled input channels read through ps_index; + the bias gradient)
 __global__ __launch_bounds__(256) void app_conv2_bwd_weight_kernel(int H, int W, int tiles_x, int n_tiles, const float* __restrict__ u,
                                                                    const float* __restrict__ dz2, float* __restrict__ partials)
 {
     __shared__ float d_lds[AC * PS_CENTER];
     __shared__ float u_lds[AC * PS_HALO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, k = lane >> 4;
-    const int d_base = plane_base(n, PS_CENTER) + k, u_base = plane_base(n, PS_HALO) + k;
+    const int d_base = plane_base(n, PS_CENTER) + k, u_base = plane_base(UP ? (n & 7) : n, PS_HALO) + k;  // UP: columns 8..15 unused
     auto d_off = [](int c) { return plane_base(c, PS_CENTER); };
     auto u_off = [](int c) { return plane_base(c, PS_HALO); };
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the next tile (dz2 centre, u with halo) travels in registers while this one's 288 MFMAs per wave run
-    float pre_d[2][AC], pre_u[3][AC];
+    float pre_d[2][AC], pre_u[3][UP ? UC : AC];
+    float bsum = 0.0f;  // UP: sum of this lane's A operands = its share of the bias gradient of channel n
     auto fetch = [&](int tile) {
         const int ty0 = (tile / tiles_x) * TH_SMALL, tx0 = (tile % tiles_x) * TW;
         tile_fetch<TW, 2>(pre_d, TH_SMALL, ty0, tx0, H, W, dz2, tid);
-        tile_fetch<RS, 3>(pre_u, TH_SMALL + 2, ty0 - 1, tx0 - 1, H, W, u, tid);
+        if constexpr (UP) {
+            const size_t hplane = (size_t)(H / 2) * (W / 2);
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+                const int pos = tid + 256 * h, ry = pos / RS, rx = pos - ry * RS;
+                const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
+                const bool in = pos < (TH_SMALL + 2) * RS && y >= 0 && y < H && x >= 0 && x < W;
+#pragma unroll
+                for (int c = 0; c < UC; c++) pre_u[h][c] = in ? u[ps_index(c, y, x, W / 2, hplane)] : 0.0f;
+            }
+        } else {
+            tile_fetch<RS, 3>(pre_u, TH_SMALL + 2, ty0 - 1, tx0 - 1, H, W, u, tid);
+        }
     };
     auto commit = [&]() {
         tile_commit<TW, 2>(d_lds, d_off, pre_d, TH_SMALL, TW, tid);
-        tile_commit<RS, 3>(u_lds, u_off, pre_u, TH_SMALL + 2, RS, tid);
+        if constexpr (UP) {
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+                const int pos = tid + 256 * h;
+                if (pos < (TH_SMALL + 2) * RS) {
+#pragma unroll
+                    for (int c = 0; c < UC; c++) u_lds[u_off(c) + pos] = pre_u[h][c];
+                }
+            }
+        } else {
+            tile_commit<RS, 3>(u_lds, u_off, pre_u, TH_SMALL + 2, RS, tid);
+        }
     };
     if ((int)blockIdx.x < n_tiles) {
         fetch(blockIdx.x);
@@ -600,6 +642,7 @@ __global__ __launch_bounds__(256) void app_conv2_bwd_weight_kernel(int H, int W,
             if (step + 1 < 32) load_step(aq[cur ^ 1], bq[cur ^ 1], step + 1);
 #pragma unroll
             for (int t = 0; t < 9; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur], bq[cur][t], acc[t], 0, 0, 0);
+            if (UP) bsum += aq[cur];
 #pragma unroll
             for (int i = 0; i < 10; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -617,12 +660,134 @@ __global__ __launch_bounds__(256) void app_conv2_bwd_weight_kernel(int H, int W,
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) red[wave * B3_PARTIAL + (t * 4 + reg) * 64 + lane] = acc[t][reg];
     __syncthreads();
-    float* out = partials + (size_t)blockIdx.x * B3_PARTIAL;
+    float* out = partials + (size_t)blockIdx.x * (UP ? UP_PARTIAL : B3_PARTIAL);
     for (int e = tid; e < B3_PARTIAL; e += 256) {
         const float v = ((red[e] + red[B3_PARTIAL + e]) + red[2 * B3_PARTIAL + e]) + red[3 * B3_PARTIAL + e];
         const int t = e >> 8, reg = (e >> 6) & 3, l = e & 63, co = 4 * (l >> 4) + reg, ci = l & 15;
         out[(t * AC + co) * AC + ci] = v;
     }
+    if constexpr (UP) {  // bias gradient: channel n, summed over the 4 pixel groups k and the 4 waves
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < AC) {
+            float v = 0.0f;
+            for (int w = 0; w < 4; w++)
+                for (int kk = 0; kk < 4; kk++) v += red[w * 64 + kk * 16 + tid];
+            out[B3_PARTIAL + tid] = v;
+        }
+    }
+}
+
+// up4 forward: feat = relu(conv3x3(ps(x), w) + b), 8 -> 16 channels: 18 MFMAs per 16 pixels, same pipeline as app_conv16_kernel
+__global__ __launch_bounds__(256) void app_up_fwd_kernel(int H, int W, int tiles_x, int n_tiles, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ feat)
+{
+    __shared__ float lds[UC * PS8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, k = lane >> 4;
+    const size_t plane = (size_t)H * W, hplane = (size_t)(H / 2) * (W / 2);
+    float wreg[18];  // A[co = n][ci = 4j + k] per tap
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) wreg[t * 2 + j] = w[(n * UC + 4 * j + k) * 9 + t];
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias[r] = b[4 * k + r];
+    float pre[3][UC];
+    auto fetch = [&](int tile) {
+        const int ty0 = (tile / tiles_x) * TH_SMALL, tx0 = (tile % tiles_x) * TW;
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+            const int pos = tid + 256 * h, ry = pos / RS, rx = pos - ry * RS;
+            const int y = ty0 - 1 + ry, xx = tx0 - 1 + rx;
+            const bool in = pos < (TH_SMALL + 2) * RS && y >= 0 && y < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int c = 0; c < UC; c++) pre[h][c] = in ? x[ps_index(c, y, xx, W / 2, hplane)] : 0.0f;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+            const int pos = tid + 256 * h;
+            if (pos < (TH_SMALL + 2) * RS) {
+#pragma unroll
+                for (int c = 0; c < UC; c++) lds[c * PS8 + pos] = pre[h][c];
+            }
+        }
+    };
+    auto store_segment = [&](const f32x4& acc, int y, int xx) {
+        if (y < H && xx < W) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) feat[(4 * k + reg) * plane + (size_t)y * W + xx] = fmaxf(acc[reg] + bias[reg], 0.0f);
+        }
+    };
+    const float* bbase = lds + k * PS8 + n;
+    auto load_tap = [&](float(&bv)[8], int row, int t) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) bv[j * 4 + s] = bbase[4 * j * PS8 + (row + t / 3) * RS + s * 16 + t % 3];
+    };
+    if ((int)blockIdx.x < n_tiles) {
+        fetch(blockIdx.x);
+        commit();
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int ty0 = (tile / tiles_x) * TH_SMALL, tx0 = (tile % tiles_x) * TW;
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) fetch(next);
+        float bq[2][8];
+        f32x4 acc[2][4];
+        load_tap(bq[0], wave * 2, 0);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) acc[r][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int step = r * 9 + t;
+                if (step + 1 < 18) load_tap(bq[(step + 1) & 1], wave * 2 + (step + 1) / 9, (step + 1) % 9);
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+                        acc[r][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t * 2 + j], bq[step & 1][j * 4 + s], acc[r][s], 0, 0, 0);
+                if (r == 1 && t >= 1 && t <= 4) store_segment(acc[0][t - 1], ty0 + wave * 2, tx0 + (t - 1) * 16 + n);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) store_segment(acc[1][s], ty0 + wave * 2 + 1, tx0 + s * 16 + n);
+        __syncthreads();
+        if (next < n_tiles) commit();
+        __syncthreads();
+    }
+}
+
+// one wave per element of dW4 [16][8][3][3] and db4 [16]: sums the weight-gradient kernel's partial rows
+__global__ __launch_bounds__(256) void app_up_reduce_kernel(const float* __restrict__ partials, int rows, float* __restrict__ dw,
+                                                            float* __restrict__ db)
+{
+    const int lane = threadIdx.x & 63, e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= AC * UC * 9 + AC) return;
+    int src;
+    if (e < AC * UC * 9) {  // dw[co][ci][t] <- partial [t][co][ci16]
+        const int co = e / (UC * 9), ci = (e / 9) % UC, t = e % 9;
+        src = (t * AC + co) * AC + ci;
+    } else {
+        src = B3_PARTIAL + (e - AC * UC * 9);
+    }
+    float v = 0.0f;
+    for (int r = lane; r < rows; r += 64) v += partials[(size_t)r * UP_PARTIAL + src];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) (e < AC * UC * 9 ? dw[e] : db[e - AC * UC * 9]) = v;
 }
 
 // One wave per output element: sums `rows` partial rows (row stride `stride`), lanes striding over the rows.
@@ -659,7 +824,8 @@ __global__ __launch_bounds__(256) void app_reduce_partials_kernel(const float* _
 // dfeat[c][hy][hx] = sum over the output pixels whose bilinear footprint contains (hy, hx): the adjoint of the upsampling,
 // as a gather (deterministic).  One thread per (hy, hx), all 16 channels.
 __global__ __launch_bounds__(256) void app_upsample_bwd_kernel(int H, int W, int Hh, int Wh, float sy, float sx,
-                                                               const float* __restrict__ du, float* __restrict__ dfeat)
+                                                               const float* __restrict__ du, const float* __restrict__ relu_of,
+                                                               float* __restrict__ dfeat)
 {
     const int hx = blockIdx.x * 64 + (threadIdx.x & 63), hy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (hx >= Wh || hy >= Hh) return;
@@ -688,7 +854,10 @@ __global__ __launch_bounds__(256) void app_upsample_bwd_kernel(int H, int W, int
     }
     const size_t hplane = (size_t)Hh * Wh;
 #pragma unroll
-    for (int c = 0; c < AC; c++) dfeat[c * hplane + (size_t)hy * Wh + hx] = acc[c];
+    for (int c = 0; c < AC; c++) {
+        const size_t o = c * hplane + (size_t)hy * Wh + hx;
+        dfeat[o] = (!relu_of || relu_of[o] > 0.0f) ? acc[c] : 0.0f;
+    }
 }
 
 // The same adjoint for the scales the network produces (about 1/2): one workgroup per 8 x 32 tile of feat.  The output-space
@@ -698,7 +867,8 @@ constexpr int UB_HT = 8, UB_WT = 32, UB_ROWS = 26, UB_COLS = 80, UB_TAPS = 5;
 inline bool upsample_bwd_tiled_ok(float sy, float sx) { return sy >= 0.41f && sx >= 0.435f; }  // regions and windows fit
 
 __global__ __launch_bounds__(256) void app_upsample_bwd_tiled_kernel(int H, int W, int Hh, int Wh, float sy, float sx,
-                                                                     const float* __restrict__ du, float* __restrict__ dfeat)
+                                                                     const float* __restrict__ du, const float* __restrict__ relu_of,
+                                                                     float* __restrict__ dfeat)
 {
     __shared__ float region[UB_ROWS * UB_COLS];
     __shared__ float rowsum[UB_ROWS * UB_WT];
@@ -758,7 +928,10 @@ __global__ __launch_bounds__(256) void app_upsample_bwd_tiled_kernel(int H, int 
         float v = 0.0f;
 #pragma unroll
         for (int j = 0; j < UB_TAPS; j++) v = __builtin_fmaf(wy[j], rowsum[min(yw + j, UB_ROWS - 1) * UB_WT + cx], v);
-        if (hx < Wh && hy < Hh) dfeat[c * hplane + (size_t)hy * Wh + hx] = v;
+        if (hx < Wh && hy < Hh) {
+            const size_t o = c * hplane + (size_t)hy * Wh + hx;
+            dfeat[o] = (!relu_of || relu_of[o] > 0.0f) ? v : 0.0f;
+        }
     }
 }
 
@@ -767,6 +940,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int MAX_PARTIAL_ROWS = 1024;
 constexpr int CONV3_BWD_GRID = 512;    // 2 workgroups (55 KB of LDS each, ~200 VGPRs) per CU
 constexpr int CONV3_FWD_GRID = 512;    // 2 workgroups (79 KB of LDS each) per CU
+constexpr int UP_FWD_GRID = 1024;      // 22 KB of LDS: 4 workgroups per CU
 constexpr int WGRAD_GRID = 512;        // 2 workgroups (80 KB of LDS each) per CU
 constexpr int CONV16_FWD_GRID = 512;  // 2 workgroups (62 KB of LDS each) per CU x 256 CUs
 constexpr int CONV16_BWD_GRID = 512;  // 2 per CU (188 VGPRs; forcing 3 waves per SIMD spills and measured slower)
@@ -790,7 +964,7 @@ void gsr_launch_appearance_forward(int H, int W, int Hh, int Wh, const float* fe
     const int tx = cdiv(W, TW), tiles = tx * cdiv(H, TH_BIG), tiles8 = tx * cdiv(H, TH_SMALL);
     const float sy = up_scale(Hh, H), sx = up_scale(Wh, W);
     float* saved_u = saved_a + (size_t)AC * H * W;
-    app_conv16_kernel<false><<<tiles8 < CONV16_FWD_GRID ? tiles8 : CONV16_FWD_GRID, 256, 0, s>>>(
+    app_conv16_kernel<0><<<tiles8 < CONV16_FWD_GRID ? tiles8 : CONV16_FWD_GRID, 256, 0, s>>>(
         H, W, Hh, Wh, sy, sx, tx, tiles8, upsample_staged_ok(sy, sx) ? 1 : 0, feat, w2, b2, saved_a, saved_u);
     app_conv3_fwd_kernel<<<tiles < CONV3_FWD_GRID ? tiles : CONV3_FWD_GRID, 256, 0, s>>>(H, W, tx, tiles, saved_a, w3, b3, image, mapping, transformed);
 }
@@ -798,7 +972,7 @@ void gsr_launch_appearance_forward(int H, int W, int Hh, int Wh, const float* fe
 void gsr_launch_appearance_backward(int H, int W, int Hh, int Wh, const float* feat, const float* w2, const float* w3, const float* image,
                                     const float* mapping, const float* saved_a, const float* g_transformed, const float* g_mapping,
                                     float* dimage, float* dfeat, float* dw2, float* db2, float* dw3, float* db3, char* scratch,
-                                    hipStream_t s)
+                                    int mask_relu, hipStream_t s)
 {
     size_t o_dz2, o_du, o_p3, o_p2;
     gsr_appearance_layout(H, W, &o_dz2, &o_du, &o_p3, &o_p2);
@@ -812,12 +986,33 @@ void gsr_launch_appearance_backward(int H, int W, int Hh, int Wh, const float* f
     const int rows2 = tiles_small < WGRAD_GRID ? tiles_small : WGRAD_GRID;
     const float* saved_u = saved_a + (size_t)AC * H * W;
     app_conv3_bwd_kernel<<<rows, 256, 0, s>>>(H, W, tx, tiles_small, saved_a, w3, image, mapping, g_transformed, g_mapping, dimage, dz2, p3);
-    app_conv2_bwd_weight_kernel<<<rows2, 256, 0, s>>>(H, W, tx, tiles_small, saved_u, dz2, p2);
-    app_conv16_kernel<true><<<tiles_small < CONV16_BWD_GRID ? tiles_small : CONV16_BWD_GRID, 256, 0, s>>>(H, W, Hh, Wh, sy, sx, tx, tiles_small, 0,
+    app_conv2_bwd_weight_kernel<false><<<rows2, 256, 0, s>>>(H, W, tx, tiles_small, saved_u, dz2, p2);
+    app_conv16_kernel<1><<<tiles_small < CONV16_BWD_GRID ? tiles_small : CONV16_BWD_GRID, 256, 0, s>>>(H, W, Hh, Wh, sy, sx, tx, tiles_small, 0,
                                                                                                  dz2, w2, nullptr, du, nullptr);
     app_reduce_partials_kernel<<<cdiv(27 * AC + AO + AC + B3_PARTIAL, 4), 256, 0, s>>>(p3, rows, p2, rows2, dw3, db3, db2, dw2);
     if (upsample_bwd_tiled_ok(sy, sx))
-        app_upsample_bwd_tiled_kernel<<<dim3(cdiv(Wh, UB_WT), cdiv(Hh, UB_HT)), 256, 0, s>>>(H, W, Hh, Wh, sy, sx, du, dfeat);
+        app_upsample_bwd_tiled_kernel<<<dim3(cdiv(Wh, UB_WT), cdiv(Hh, UB_HT)), 256, 0, s>>>(H, W, Hh, Wh, sy, sx, du, mask_relu ? feat : nullptr, dfeat);
     else
-        app_upsample_bwd_kernel<<<dim3(cdiv(Wh, 64), cdiv(Hh, 4)), 256, 0, s>>>(H, W, Hh, Wh, sy, sx, du, dfeat);
+        app_upsample_bwd_kernel<<<dim3(cdiv(Wh, 64), cdiv(Hh, 4)), 256, 0, s>>>(H, W, Hh, Wh, sy, sx, du, mask_relu ? feat : nullptr, dfeat);
 }
+
+size_t gsr_appearance_up_scratch_bytes_impl() { return (size_t)WGRAD_GRID * UP_PARTIAL * sizeof(float); }
+
+void gsr_launch_appearance_up_forward(int Hf, int Wf, const float* x, const float* w, const float* b, float* feat, hipStream_t s)
+{
+    const int tx = cdiv(Wf, TW), tiles = tx * cdiv(Hf, TH_SMALL);
+    app_up_fwd_kernel<<<tiles < UP_FWD_GRID ? tiles : UP_FWD_GRID, 256, 0, s>>>(Hf, Wf, tx, tiles, x, w, b, feat);
+}
+
+void gsr_launch_appearance_up_backward(int Hf, int Wf, const float* x, const float* w, const float* dz, float* dx, float* dw, float* db,
+                                       char* scratch, hipStream_t s)
+{
+    const int tx = cdiv(Wf, TW), tiles = tx * cdiv(Hf, TH_SMALL);
+    const int rows = tiles < WGRAD_GRID ? tiles : WGRAD_GRID;
+    float* partials = (float*)scratch;
+    app_conv2_bwd_weight_kernel<true><<<rows, 256, 0, s>>>(Hf, Wf, tx, tiles, x, dz, partials);
+    app_conv16_kernel<2><<<tiles < CONV16_BWD_GRID ? tiles : CONV16_BWD_GRID, 256, 0, s>>>(Hf, Wf, Hf / 2, Wf / 2, 0.0f, 0.0f, tx, tiles, 0, dz, w,
+                                                                                           nullptr, dx, nullptr);
+    app_up_reduce_kernel<<<cdiv(AC * UC * 9 + AC, 4), 256, 0, s>>>(partials, rows, dw, db);
+}
+

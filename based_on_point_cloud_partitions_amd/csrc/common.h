@@ -180,7 +180,11 @@ void gsr_launch_appearance_forward(int H, int W, int Hh, int Wh, const float* fe
 void gsr_launch_appearance_backward(int H, int W, int Hh, int Wh, const float* feat, const float* w2, const float* w3, const float* image,
                                     const float* mapping, const float* saved_a, const float* g_transformed, const float* g_mapping,
                                     float* dimage, float* dfeat, float* dw2, float* db2, float* dw3, float* db3, char* scratch,
-                                    hipStream_t s);
+                                    int mask_relu, hipStream_t s);
+size_t gsr_appearance_up_scratch_bytes_impl();
+void gsr_launch_appearance_up_forward(int Hf, int Wf, const float* x, const float* w, const float* b, float* feat, hipStream_t s);
+void gsr_launch_appearance_up_backward(int Hf, int Wf, const float* x, const float* w, const float* dz, float* dx, float* dw, float* db,
+                                       char* scratch, hipStream_t s);
 size_t gsr_loss_scratch_layout(int C, int H, int W, size_t* maps_off, size_t* partials_off);
 void gsr_launch_loss_forward(int C, int H, int W, const float* img1, const float* img2, const float* img_l1, float lambda,
                              float* maps, float* partials, float* out3, hipStream_t s);

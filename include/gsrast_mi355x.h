@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 7
+#define GSR_ABI_VERSION 8
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -137,7 +137,9 @@ int gsr_loss_backward(int C, int H, int W, const float* img1, const float* img2,
  * float32 on the device.  The forward keeps `a` in `saved` (gsr_appearance_saved_bytes) for the backward, which returns the
  * gradients of feat, the four parameter tensors and the image -- for the image the direct `mapping * dL_dtransformed` term;
  * the path through the network's down-sampled input is upstream of feat and stays with the caller's autograd.
- * dL_dmapping may be NULL (train.py uses only the transformed image). */
+ * dL_dmapping may be NULL (train.py uses only the transformed image).  mask_relu_of_feat != 0 zeroes dL_dfeat wherever
+ * feat <= 0, i.e. returns the gradient of the pre-activation of the ReLU that produced feat (what gsr_appearance_up_backward
+ * takes), saving the separate masking pass. */
 size_t gsr_appearance_saved_bytes(int H, int W);
 size_t gsr_appearance_scratch_bytes(int H, int W);
 int gsr_appearance_tail_forward(int H, int W, int feat_h, int feat_w, const float* feat, const float* conv2_weight,
@@ -147,7 +149,16 @@ int gsr_appearance_tail_backward(int H, int W, int feat_h, int feat_w, const flo
                                  const float* conv3_weight, const float* image, const float* mapping, const void* saved,
                                  size_t saved_bytes, const float* dL_dtransformed, const float* dL_dmapping, float* dL_dimage,
                                  float* dL_dfeat, float* dL_dconv2_weight, float* dL_dconv2_bias, float* dL_dconv3_weight,
-                                 float* dL_dconv3_bias, void* scratch, size_t scratch_bytes, void* stream);
+                                 float* dL_dconv3_bias, void* scratch, size_t scratch_bytes, int mask_relu_of_feat, void* stream);
+
+/* The block that produces feat: `up4` of the same network, UpsampleBlock(32, 16) = PixelShuffle(2) -> Conv2d(8, 16, 3, padding=1)
+ * -> ReLU (scene/ptgs/appearance_network.py:20-29,45).  x is [32][feat_h/2][feat_w/2], weight [16][8][3][3], bias [16], feat
+ * [16][feat_h][feat_w] (feat_h, feat_w even).  The backward takes dz = dL/dfeat already masked by feat > 0
+ * (gsr_appearance_tail_backward with mask_relu_of_feat) and returns the gradients of x, weight and bias. */
+size_t gsr_appearance_up_scratch_bytes(int feat_h, int feat_w);
+int gsr_appearance_up_forward(int feat_h, int feat_w, const float* x, const float* weight, const float* bias, float* feat, void* stream);
+int gsr_appearance_up_backward(int feat_h, int feat_w, const float* x, const float* weight, const float* dz, float* dL_dx,
+                               float* dL_dweight, float* dL_dbias, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Optimizer step of the training loop: torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of
  * scene/gaussian_model.py:164-175 / train.py:155-157 for ALL parameter tensors in one launch -- dense Adam, weight_decay = 0,

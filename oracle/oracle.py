@@ -341,3 +341,28 @@ def appearance_tail_backward(saved, w2, w3, image, g_transformed, g_mapping=None
     du, gw2, gb2 = _conv3x3_backward(u, w2, dz2)
     _, h, w = saved["feat_shape"]
     return dict(feat=_bilinear_upsample_adjoint(du, h, w), w2=gw2, b2=gb2, w3=gw3, b3=gb3, image=(g * m).astype(np.float32))
+
+
+def pixel_shuffle2(x):
+    """torch.nn.PixelShuffle(2): [4c, h, w] -> [c, 2h, 2w], out[c][2y + i][2x + j] = x[4c + 2i + j][y][x]."""
+    C4, h, w = x.shape
+    return np.ascontiguousarray(x.reshape(C4 // 4, 2, 2, h, w).transpose(0, 3, 1, 4, 2).reshape(C4 // 4, 2 * h, 2 * w))
+
+
+def _pixel_unshuffle2(g):
+    C, H, W = g.shape
+    return np.ascontiguousarray(g.reshape(C, H // 2, 2, W // 2, 2).transpose(0, 2, 4, 1, 3).reshape(4 * C, H // 2, W // 2))
+
+
+def up_block_forward(x, w, b):
+    """UpsampleBlock.forward (scene/ptgs/appearance_network.py:20-29): PixelShuffle(2) -> Conv2d(3x3, padding 1) -> ReLU."""
+    x, w, b = (np.ascontiguousarray(t, np.float32) for t in (x, w, b))
+    ps = pixel_shuffle2(x)
+    return np.maximum(_conv3x3(ps, w, b), np.float32(0)), ps
+
+
+def up_block_backward(ps, w, y, g):
+    """Gradients of up_block_forward w.r.t. x, w, b given g = dL/dy (y = its output, for the ReLU mask)."""
+    dz = np.where(y > 0, np.ascontiguousarray(g, np.float32), np.float32(0)).astype(np.float32)
+    dps, gw, gb = _conv3x3_backward(ps, w, dz)
+    return _pixel_unshuffle2(dps), gw, gb

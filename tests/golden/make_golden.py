@@ -163,6 +163,17 @@ def ref_appearance():
                     f"g_image_direct{k}": (image.grad - via_input).numpy()})
         k += 1
     out["n"] = np.array(k)
+    # the block that produces feat: UpsampleBlock(32, 16) alone (values + autograd gradients)
+    torch.manual_seed(7)
+    up = an.UpsampleBlock(32, 16)
+    with torch.no_grad():
+        up.conv.weight.mul_(2.0); up.conv.bias.add_(0.1 * torch.randn(16))
+    ux = torch.randn(1, 32, 9, 13).requires_grad_(True)
+    uy = up(ux)
+    ug = torch.randn_like(uy)
+    uy.backward(ug)
+    out.update(up_x=ux.detach()[0].numpy(), up_w=up.conv.weight.detach().numpy(), up_b=up.conv.bias.detach().numpy(), up_y=uy.detach()[0].numpy(),
+               up_g=ug[0].numpy(), up_gx=ux.grad[0].numpy(), up_gw=up.conv.weight.grad.numpy(), up_gb=up.conv.bias.grad.numpy())
     # the module's parameter names and shapes (what a stand-in network must offer to appearance.py)
     out["state_keys"] = np.array([f"{name}:{tuple(v.shape)}" for name, v in an.AppearanceNetwork(3 + 64, 3).state_dict().items()])
     np.savez_compressed(os.path.join(HERE, "ref_appearance.npz"), **out)

@@ -28,6 +28,15 @@ def test_oracle_matches_reference_appearance_network():
             assert np.abs(g[name] - want).max() <= 5e-6 * np.abs(want).max(), name
 
 
+def test_oracle_up_block_matches_reference_module():
+    fx = np.load(os.path.join(G, "ref_appearance.npz"))
+    y, ps = oracle.up_block_forward(fx["up_x"], fx["up_w"], fx["up_b"])
+    assert np.abs(y - fx["up_y"]).max() < 3e-6
+    gx, gw, gb = oracle.up_block_backward(ps, fx["up_w"], y, fx["up_g"])
+    for got, key in ((gx, "up_gx"), (gw, "up_gw"), (gb, "up_gb")):
+        assert np.abs(got - fx[key]).max() <= 5e-6 * np.abs(fx[key]).max(), key
+
+
 def test_oracle_bilinear_is_torchs():
     import torch.nn.functional as F
 
@@ -101,6 +110,47 @@ def test_hip_tail_matches_oracle(H, W, fh, fw, with_r2):
     for name in ("feat", "w2", "b2", "w3", "b3", "image"):
         scale = max(np.abs(want[name]).max(), 1e-6)
         assert np.abs(g[name] - want[name]).max() <= 2e-5 * scale, (name, np.abs(g[name] - want[name]).max(), scale)
+
+
+def _run_hip_up_tail(x, w4, b4, w2, b2, w3, b3, image, r1, r2):
+    from based_on_point_cloud_partitions_amd.appearance import appearance_up_tail
+
+    t = lambda a: torch.tensor(a, device="cuda", requires_grad=True)
+    ins = [t(a) for a in (x, w4, b4, w2, b2, w3, b3, image)]
+    transformed, mapping = appearance_up_tail(*ins)
+    H, W = image.shape[1:]
+    st = transformed.grad_fn.saved_tensors  # x, w4, feat, w2, w3, image, mapping, saved
+    feat = st[2].cpu().numpy()
+    saved_a = st[7].view(torch.float32)[:16 * H * W].view(16, H, W).cpu().numpy()
+    loss = (transformed * torch.tensor(r1, device="cuda")).sum() + (mapping * torch.tensor(r2, device="cuda")).sum()
+    loss.backward()
+    names = ("x", "w4", "b4", "w2", "b2", "w3", "b3", "image")
+    return mapping.detach().cpu().numpy(), transformed.detach().cpu().numpy(), feat, saved_a, {n: v.grad.cpu().numpy() for n, v in zip(names, ins)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,h,w", [(70, 101, 16, 24), (33, 65, 8, 16), (9, 7, 1, 1), (200, 333, 48, 80), (1080, 1920, 264, 480)])
+def test_hip_up_block_and_tail_match_oracle(H, W, h, w):
+    """`up4` + tail as one node (x = up3's output [32,h,w] -> feat [16,2h,2w] -> image resolution) against the oracle's two stages."""
+    rng = np.random.default_rng(H * 7 + W)
+    f32 = lambda a: a.astype(np.float32)
+    x = f32(np.maximum(rng.normal(0.1, 1.0, (32, h, w)), 0))
+    w4, b4 = f32(rng.normal(0, 0.35, (16, 8, 3, 3))), f32(rng.normal(0, 0.3, 16))
+    _, w2, b2, w3, b3, image, r1, r2 = _random_case(H, W, 1, 1, H + W)
+    m, t, feat, saved_a, g = _run_hip_up_tail(x, w4, b4, w2, b2, w3, b3, image, r1, r2)
+    want_feat, ps = oracle.up_block_forward(x, w4, b4)
+    assert np.abs(feat - want_feat).max() <= 1e-5 * max(1.0, np.abs(want_feat).max())
+    # both ReLU masks are discontinuities: the oracle continues from the activations the kernels produced (checked above / below)
+    want_m, want_t, saved = oracle.appearance_tail_forward(feat, w2, b2, w3, b3, image)
+    assert np.abs(m - want_m).max() < 5e-6 and np.abs(t - want_t).max() < 5e-6  # (pre-activations reach +-30 here)
+    assert np.abs(saved_a - saved["a"]).max() <= 1e-5 * max(1.0, np.abs(saved["a"]).max())
+    saved["a"] = saved_a
+    want = oracle.appearance_tail_backward(saved, w2, w3, image, r1, r2)
+    gx, gw4, gb4 = oracle.up_block_backward(ps, w4, feat, want["feat"])
+    want.update(x=gx, w4=gw4, b4=gb4)
+    for name in ("x", "w4", "b4", "w2", "b2", "w3", "b3", "image"):
+        scale = max(np.abs(want[name]).max(), 1e-6)
+        assert np.abs(g[name] - want[name]).max() <= 3e-5 * scale, (name, np.abs(g[name] - want[name]).max(), scale)
 
 
 def _model(seed):
