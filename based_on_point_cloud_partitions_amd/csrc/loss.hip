@@ -45,6 +45,16 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(int C, int H, int W, 
     const size_t plane = (size_t)H * W;
     const float* a = img1 + (size_t)c * plane;
     const float* b = img2 + (size_t)c * plane;
+    // the separate L1 image's values for this thread's outputs: requested now, used in the epilogue (a load issued there
+    // would leave its whole latency exposed at the end of the workgroup)
+    float xl_pre[RPT];
+    if (img_l1) {
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            const int gy = y0 + (int)(threadIdx.x >> 5) * RPT + j, gx = x0 + (int)(threadIdx.x & 31);
+            xl_pre[j] = (gx < W && gy < H) ? img_l1[(size_t)c * plane + (size_t)gy * W + gx] : 0.f;
+        }
+    }
     for (int i = threadIdx.x; i < TINY * TIN; i += 256) {
         const int ly = i / TIN, lx = i - ly * TIN;
         const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
@@ -115,7 +125,7 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(int C, int H, int W, 
             maps[2 * CP + id] = 2.f * A * inv;                                                               // d m / d E[xy]
             m_sum += m;
             // L1 on the rendered image itself, or on a separate image (the appearance-decoupled one of train.py:112-116)
-            const float xl = img_l1 ? img_l1[id] : s_x[rg + j + HALO][tx + HALO];
+            const float xl = img_l1 ? xl_pre[j] : s_x[rg + j + HALO][tx + HALO];
             l1_sum += fabsf(xl - s_y[rg + j + HALO][tx + HALO]);
         }
     }
@@ -164,6 +174,17 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(int C, int H, int W,
     const int x0 = blockIdx.x * TB, y0 = blockIdx.y * TBY, c = blockIdx.z;
     const size_t plane = (size_t)H * W, CP = (size_t)C * plane;
     const float* mp = maps + (size_t)c * plane;
+    // the epilogue's per-pixel inputs, requested before the filtering instead of after it
+    float x_pre[RPT], y_pre[RPT], xl_pre[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+        const int gy = y0 + (int)(threadIdx.x >> 5) * RPT + j, gx = x0 + (int)(threadIdx.x & 31);
+        const bool in = gx < W && gy < H;
+        const size_t id = in ? (size_t)c * plane + (size_t)gy * W + gx : 0;
+        x_pre[j] = in ? img1[id] : 0.f;
+        y_pre[j] = in ? img2[id] : 0.f;
+        xl_pre[j] = (in && img_l1) ? img_l1[id] : 0.f;
+    }
     for (int i = threadIdx.x; i < TINY * TIN; i += 256) {
         const int ly = i / TIN, lx = i - ly * TIN;
         const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
@@ -214,8 +235,8 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(int C, int H, int W,
         const int gy = y0 + rg + j;
         if (gx < W && gy < H) {
             const size_t id = (size_t)c * plane + (size_t)gy * W + gx;
-            const float x = img1[id], y = img2[id];
-            const float d = (img_l1 ? img_l1[id] : x) - y;
+            const float x = x_pre[j], y = y_pre[j];
+            const float d = (img_l1 ? xl_pre[j] : x) - y;
             const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
             const float g_ssim = (-lambda * invN) * (acc[j][0] + 2.f * x * acc[j][1] + y * acc[j][2]);
             const float g_l1 = ((1.0f - lambda) * invN) * sgn;
