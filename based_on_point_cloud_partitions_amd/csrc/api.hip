@@ -587,6 +587,17 @@ int gsr_appearance_up_backward(int feat_h, int feat_w, const float* x, const flo
     return check_hip("appearance_up_backward");
 }
 
+size_t gsr_mse_scratch_bytes(int rows) { return rows > 0 ? gsr_mse_scratch_bytes_impl(rows) : 0; }
+
+int gsr_mse(int rows, int64_t n, const float* img1, const float* img2, float* out, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (rows <= 0 || n <= 0 || rows > 65535) return fail(-1, "mse: rows must be in 1..65535 and n positive");
+    if (!img1 || !img2 || !out || !scratch) return fail(-1, "NULL required pointer");
+    if (scratch_bytes < gsr_mse_scratch_bytes(rows)) return fail(-3, "mse scratch too small");
+    gsr_launch_mse(rows, (long long)n, img1, img2, out, (double*)scratch, (hipStream_t)stream);
+    return check_hip("mse");
+}
+
 int gsr_adam_step(int n_tensors, const gsr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream)
 {
     static_assert(sizeof(gsr_adam_tensor) == sizeof(GsrAdamTensorHost), "ABI struct mismatch");

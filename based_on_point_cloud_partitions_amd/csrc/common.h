@@ -182,6 +182,8 @@ void gsr_launch_appearance_backward(int H, int W, int Hh, int Wh, const float* f
                                     float* dimage, float* dfeat, float* dw2, float* db2, float* dw3, float* db3, char* scratch,
                                     int mask_relu, hipStream_t s);
 size_t gsr_appearance_up_scratch_bytes_impl();
+size_t gsr_mse_scratch_bytes_impl(int rows);
+void gsr_launch_mse(int rows, long long n, const float* a, const float* b, float* out, double* partials, hipStream_t s);
 void gsr_launch_appearance_up_forward(int Hf, int Wf, const float* x, const float* w, const float* b, float* feat, hipStream_t s);
 void gsr_launch_appearance_up_backward(int Hf, int Wf, const float* x, const float* w, const float* dz, float* dx, float* dw, float* db,
                                        char* scratch, hipStream_t s);

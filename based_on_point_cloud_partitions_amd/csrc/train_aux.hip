@@ -76,6 +76,44 @@ __global__ void __launch_bounds__(256) compact_rows_kernel(int P, const uint8_t*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// mse of utils/image_utils.py:17-18: (((img1 - img2)) ** 2).view(rows, -1).mean(1) -- one value per leading index (per
+// channel for a [3,H,W] image as train.py:227 passes it, per image for the [1,3,H,W] tensors of metrics.py:93).  Two fixed
+// order stages (256 partial sums per row in double, then their sum): bitwise reproducible.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int MSE_PARTS = 256;
+
+__global__ void __launch_bounds__(256) mse_partial_kernel(long long n, const float* __restrict__ a, const float* __restrict__ b,
+                                                          double* __restrict__ partials)
+{
+    __shared__ double s_w[4];
+    const int row = blockIdx.y, part = blockIdx.x;
+    const long long per = (n + MSE_PARTS - 1) / MSE_PARTS, lo = part * per, hi = lo + per < n ? lo + per : n;
+    const float* pa = a + (size_t)row * n;
+    const float* pb = b + (size_t)row * n;
+    double acc = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float d = pa[i] - pb[i];
+        acc += (double)(d * d);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)row * MSE_PARTS + part] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
+
+__global__ void __launch_bounds__(256) mse_final_kernel(long long n, const double* __restrict__ partials, float* __restrict__ out)
+{
+    __shared__ double s_w[4];
+    double acc = partials[(size_t)blockIdx.x * MSE_PARTS + threadIdx.x];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)((((s_w[0] + s_w[1]) + s_w[2]) + s_w[3]) / (double)n);
+}
+
 }  // namespace
 
 void gsr_launch_densification_stats(int P, const int* radii, const float* vgrad, float* max_radii2D, float* accum, float* denom, hipStream_t s)
@@ -103,3 +141,12 @@ void gsr_launch_compact_rows(int P, const uint8_t* keep, const uint32_t* block_o
             hipLaunchKernelGGL(compact_rows_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, keep, block_offsets, a);
     }
 }
+
+size_t gsr_mse_scratch_bytes_impl(int rows) { return (size_t)rows * MSE_PARTS * sizeof(double); }
+
+void gsr_launch_mse(int rows, long long n, const float* a, const float* b, float* out, double* partials, hipStream_t s)
+{
+    mse_partial_kernel<<<dim3(MSE_PARTS, rows), 256, 0, s>>>(n, a, b, partials);
+    mse_final_kernel<<<rows, 256, 0, s>>>(n, partials, out);
+}
+

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 8
+#define GSR_ABI_VERSION 9
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -159,6 +159,12 @@ size_t gsr_appearance_up_scratch_bytes(int feat_h, int feat_w);
 int gsr_appearance_up_forward(int feat_h, int feat_w, const float* x, const float* weight, const float* bias, float* feat, void* stream);
 int gsr_appearance_up_backward(int feat_h, int feat_w, const float* x, const float* weight, const float* dz, float* dL_dx,
                                float* dL_dweight, float* dL_dbias, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Evaluation metric of train.py:227 / metrics.py:93: mse of utils/image_utils.py:17-18,
+ * out[r] = mean over n elements of (img1[r][i] - img2[r][i])^2 for r < rows; psnr = 20 log10(1 / sqrt(mse)) (:20-22) is left to
+ * the caller.  Sums are taken in double in a fixed order. */
+size_t gsr_mse_scratch_bytes(int rows);
+int gsr_mse(int rows, int64_t n, const float* img1, const float* img2, float* out, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Optimizer step of the training loop: torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of
  * scene/gaussian_model.py:164-175 / train.py:155-157 for ALL parameter tensors in one launch -- dense Adam, weight_decay = 0,
