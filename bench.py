@@ -56,12 +56,9 @@ def higher_msb(n):
     return msb
 
 
-def cpu_baseline(cfg, g, cam, dL):
-    """The oracle (a CPU port of the reference algorithm; the reference has no CPU path) on ONE step of the same workload."""
+def _oracle_step(g, cam, dL):
     from oracle import oracle
 
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     t0 = time.perf_counter()
     st = oracle.forward(g.xyz.numpy(), g.opacities.numpy(), shs=g.shs.numpy(), scales=g.scales.numpy(),
                         rotations=g.rotations.numpy(), viewmatrix=cam.world_view_transform.numpy(),
@@ -70,11 +67,47 @@ def cpu_baseline(cfg, g, cam, dL):
                         tanfovy=cam.tanfovy, sh_degree=3)
     t1 = time.perf_counter()
     oracle.backward(st, dL)
-    t2 = time.perf_counter()
-    stats = {"pair_visits": int(st["stats"][0]), "blended_pairs": int(st["stats"][1])}  # camera 0, reference algorithm
-    return {"value": 1.0 / (t2 - t0), "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"1 raster step (camera 0 of the {cfg['P']}-Gaussian {cfg['W']}x{cfg['H']} workload): "
-                      f"forward {t1 - t0:.2f} s + backward {t2 - t1:.2f} s, OpenMP over Gaussians/tiles"}, stats
+    return t1 - t0, time.perf_counter() - t1, st
+
+
+def cpu_baseline(cfg, g, cams, dL, n_steps=4):
+    """The oracle (a CPU port of the reference algorithm; the reference has no CPU path) on a bounded sample of the same workload:
+    `n_steps` raster steps (cameras 0..n_steps-1) with every host thread, plus -- SURVEY.md §8(d) -- one step of the small
+    reference-runnable case (cfg1: 10k Gaussians, 256x256) with one thread and with all of them, so the OpenMP scaling is visible."""
+    from oracle import oracle
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    avail = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(avail))
+    # the box may grant fewer CPUs than it shows (a container's CPU share): take the thread count that is fastest on one step
+    tried = {}
+    for threads in sorted({avail, min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True):
+        oracle.set_threads(threads)
+        f, b, _ = _oracle_step(g, cams[0], dL)
+        tried[threads] = round(f + b, 3)
+    cores = min(tried, key=tried.get)
+    oracle.set_threads(cores)
+    fwd = bwd = 0.0
+    for i in range(n_steps):
+        f, b, st = _oracle_step(g, cams[i % len(cams)], dL)
+        fwd, bwd = fwd + f, bwd + b
+        if i == 0:
+            stats = {"pair_visits": int(st["stats"][0]), "blended_pairs": int(st["stats"][1])}  # camera 0, reference algorithm
+    small_g = syn.make_gaussians(10_000, seed=0)
+    small_cam = syn.ring_cameras(4, 256, 256, 160.0)[0]
+    small_dL = np.random.default_rng(1).standard_normal((3, 256, 256)).astype(np.float32)
+    small = {}
+    for label, threads in (("1_thread", 1), (f"{cores}_threads", cores)):
+        oracle.set_threads(threads)
+        _oracle_step(small_g, small_cam, small_dL)  # warm
+        f, b, _ = _oracle_step(small_g, small_cam, small_dL)
+        small[label + "_it_per_s"] = round(1.0 / (f + b), 2)
+    oracle.set_threads(cores)
+    return {"value": n_steps / (fwd + bwd), "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"{n_steps} raster steps (cameras 0..{n_steps - 1} of the {cfg['P']}-Gaussian {cfg['W']}x{cfg['H']} workload): "
+                      f"forward {fwd:.2f} s + backward {bwd:.2f} s in all, OpenMP over Gaussians/tiles; "
+                      f"thread count chosen from one step each: {tried} s",
+            "cfg1_10k_gaussians_256x256": small}, stats
 
 
 def torch_l1_ssim(img, gt, lam, l1_image=None):
@@ -467,7 +500,7 @@ def main():
         if full is not None:
             out["full_step"] = full
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], pairs = cpu_baseline(cfg, g, cams[0], dL_cpu.numpy())
+            out["cpu_baseline"], pairs = cpu_baseline(cfg, g, cams, dL_cpu.numpy())
             # the blend kernels next to the fp32 vector peak.  Pair visits = (tile list entry, pixel) pairs the
             # reference's loop evaluates until the pixel is done (oracle count, camera 0); ~11 flops per visit (power) and ~30
             # more per blended pair in the forward, ~60 in the backward.

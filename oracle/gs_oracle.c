@@ -29,6 +29,9 @@
 #include <string.h>
 #include <float.h>
 #include <limits.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define BLOCK_X 16 /* cuda_rasterizer/config.h:15 */
 #define BLOCK_Y 16 /* cuda_rasterizer/config.h:16 */
@@ -1075,3 +1078,23 @@ void orc_l1_ssim_loss(int C, int H, int W, const float* img1, const float* img2,
     }
     free(dmu1); free(de11); free(de12);
 }
+
+/* Thread count of the OpenMP loops above (bench.py's cpu_baseline times one thread next to all of them). */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+

@@ -366,3 +366,11 @@ def up_block_backward(ps, w, y, g):
     dz = np.where(y > 0, np.ascontiguousarray(g, np.float32), np.float32(0)).astype(np.float32)
     dps, gw, gb = _conv3x3_backward(ps, w, dz)
     return _pixel_unshuffle2(dps), gw, gb
+
+
+def set_threads(n):
+    """Thread count of the C restatement's OpenMP loops; returns the previous maximum."""
+    prev = int(lib().orc_max_threads())
+    lib().orc_set_threads(int(n))
+    return prev
+
