@@ -227,3 +227,22 @@ def test_densify_and_prune_matches_the_reference_code_path():
     assert float(torch.sigmoid(a._opacity.detach()).max()) <= 0.01 + 1e-6
     st = a.optimizer.state[a._opacity]
     assert float(st["exp_avg"].abs().max()) == 0.0 and a.optimizer.param_groups[3]["params"][0] is a._opacity
+
+
+@pytest.mark.gpu
+def test_densify_and_prune_with_nothing_selected_and_with_everything_pruned():
+    from based_on_point_cloud_partitions_amd import densify
+
+    m = _Model(1000, "cuda", seed=1)
+    m.percent_dense = 0.01
+    m.xyz_gradient_accum = torch.zeros(1000, 1, device="cuda")
+    m.denom = torch.ones(1000, 1, device="cuda")
+    m.max_radii2D = torch.zeros(1000, device="cuda")
+    before = m._xyz.detach().clone()
+    densify.densify_and_prune(m, 1e9, 0.0, 5.0, None)  # nothing cloned, split or pruned: empty gathers everywhere
+    assert torch.equal(m._xyz.detach(), before) and m.optimizer.state[m._xyz]["exp_avg"].shape == (1000, 3)
+    m.xyz_gradient_accum = torch.ones(1000, 1, device="cuda")
+    densify.densify_and_prune(m, 0.0, 2.0, 5.0, 1)  # every point selected, then every point pruned (opacity < 2)
+    assert m._xyz.shape == (0, 3) and m.max_radii2D.shape == (0,) and m.optimizer.state[m._xyz]["exp_avg_sq"].shape == (0, 3)
+    densify.reset_opacity(m)  # on an empty model
+    assert m._opacity.shape == (0, 1)
