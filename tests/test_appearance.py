@@ -153,6 +153,35 @@ def test_hip_up_block_and_tail_match_oracle(H, W, h, w):
         assert np.abs(g[name] - want[name]).max() <= 3e-5 * scale, (name, np.abs(g[name] - want[name]).max(), scale)
 
 
+def _sweep_cases():
+    rng = np.random.default_rng(2026)
+    cases = []
+    for i in range(12):
+        H, W = int(rng.integers(1, 700)), int(rng.integers(1, 900))
+        if i % 3 == 0:  # the network's own geometry: feat = 16 * (size // 32), at least 2
+            fh, fw = max(2, 16 * (H // 32)), max(2, 16 * (W // 32))
+        else:  # arbitrary ratios, up- and down-sampling: the generic (unstaged / untiled) paths
+            fh, fw = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        cases.append((H, W, fh, fw))
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,fh,fw", _sweep_cases())
+def test_hip_tail_random_sizes(H, W, fh, fw):
+    """Ragged tiles, several tiles per persistent workgroup (more than 512 tiles), staged and generic interpolation paths."""
+    feat, w2, b2, w3, b3, image, r1, r2 = _random_case(H, W, fh, fw, 31 * H + W)
+    m, t, g = _run_hip(feat, w2, b2, w3, b3, image, r1, r2)
+    want_m, want_t, saved = oracle.appearance_tail_forward(feat, w2, b2, w3, b3, image)
+    assert np.abs(m - want_m).max() < 6e-6 and np.abs(t - want_t).max() < 6e-6  # (contract: 1e-4)
+    assert np.abs(g["saved_a"] - saved["a"]).max() <= 1e-5 * max(1.0, np.abs(saved["a"]).max())
+    saved["a"] = g["saved_a"]
+    want = oracle.appearance_tail_backward(saved, w2, w3, image, r1, r2)
+    for name in ("feat", "w2", "b2", "w3", "b3", "image"):
+        scale = max(np.abs(want[name]).max(), 1e-6)
+        assert np.abs(g[name] - want[name]).max() <= 3e-5 * scale, (name, np.abs(g[name] - want[name]).max(), scale)
+
+
 def _model(seed):
     from based_on_point_cloud_partitions_amd.synthetic import make_appearance_model
 
