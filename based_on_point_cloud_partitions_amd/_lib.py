@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 
@@ -63,6 +63,9 @@ PROTOTYPES = {
     "gsr_appearance_up_scratch_bytes": (c_size, [c_int, c_int]),
     "gsr_appearance_up_forward": (c_int, [c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
     "gsr_appearance_up_backward": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_size, c_void_p]),
+    "gsr_bias_relu_scratch_bytes": (c_size, [c_int]),
+    "gsr_bias_relu_forward": (c_int, [c_int, c_i64, c_void_p, c_void_p, c_void_p]),
+    "gsr_bias_relu_backward": (c_int, [c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_mse_scratch_bytes": (c_size, [c_int]),
     "gsr_mse": (c_int, [c_int, ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_knn_scratch_bytes": (c_size, [c_int]),

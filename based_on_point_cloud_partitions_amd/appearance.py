@@ -121,6 +121,61 @@ class _AppearanceUpTail(torch.autograd.Function):
         return d_x, d_w4, d_b4, d_w2, d_b2, d_w3, d_b3, d_image
 
 
+class _BiasReLU(torch.autograd.Function):
+    """relu(x + bias[c]) for x [1,C,H,W] fresh from a bias-free convolution (written in place), with dz and the bias gradient from one
+    kernel in the backward -- instead of torch's bias add, ReLU, threshold_backward and bias-gradient reduction per layer."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        lib = _lib.load()
+        C, n = x.shape[1], x.shape[2] * x.shape[3]
+        with torch.cuda.device(x.device):
+            s = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(lib.gsr_bias_relu_forward(C, n, _p(x), _p(bias), s), "gsr_bias_relu_forward")
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        lib = _lib.load()
+        C, n = y.shape[1], y.shape[2] * y.shape[3]
+        g = g.contiguous()
+        with torch.cuda.device(y.device):
+            dz = torch.empty_like(y)
+            db = torch.empty(C, dtype=torch.float32, device=y.device)
+            scratch = torch.empty(lib.gsr_bias_relu_scratch_bytes(C), dtype=torch.uint8, device=y.device)
+            s = ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
+            _lib.check(lib.gsr_bias_relu_backward(C, n, _p(g), _p(y), _p(dz), _p(db), _p(scratch), scratch.numel(), s), "gsr_bias_relu_backward")
+        return dz, db
+
+
+def _conv_bias_relu(conv, x):
+    """relu(conv(x)) for a plain 3x3 Conv2d followed by nn.ReLU: the module's own weights, torch's convolution, fused bias + ReLU."""
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return _BiasReLU.apply(y, conv.bias)
+
+
+def _plain_conv(conv):
+    return isinstance(conv, torch.nn.Conv2d) and conv.bias is not None and conv.padding_mode == "zeros" and conv.weight.dtype == torch.float32
+
+
+def _head(net, x):
+    """conv1 + up1..up3 (appearance_network.py:48-51).  When the layers are the reference's (Conv2d -> ReLU, PixelShuffle -> Conv2d ->
+    ReLU) the convolutions stay torch's and bias + ReLU are fused around them; any other module is simply called."""
+    ups = (net.up1, net.up2, net.up3)
+    standard = _plain_conv(net.conv1) and isinstance(net.relu, torch.nn.ReLU) and x.is_cuda and all(
+        isinstance(getattr(u, "pixel_shuffle", None), torch.nn.PixelShuffle) and _plain_conv(getattr(u, "conv", None)) and
+        isinstance(getattr(u, "relu", None), torch.nn.ReLU) and len(list(u.children())) == 3 for u in ups)
+    if not standard:
+        return net.up3(net.up2(net.up1(net.relu(net.conv1(x)))))
+    h = _conv_bias_relu(net.conv1, x)
+    for u in ups:
+        h = _conv_bias_relu(u.conv, u.pixel_shuffle(h))
+    return h
+
+
 def appearance_up_tail(x, up_weight, up_bias, conv2_weight, conv2_bias, conv3_weight, conv3_bias, image):
     """(transformed_image, mapping_image) from `up3`'s output [32,h,w] (appearance_network.py:51) and the rendered image: `up4` + tail."""
     if x.dim() != 3 or x.shape[0] != 32 or tuple(up_weight.shape) != (16, 8, 3, 3) or tuple(up_bias.shape) != (16,):
@@ -142,7 +197,7 @@ def decouple_appearance(image, gaussians, view_idx):
     crop_image_down = F.interpolate(image[None], size=(h, w), mode="bilinear", align_corners=True)[0]
     x = torch.cat([crop_image_down, appearance_embedding[None].repeat(h, w, 1).permute(2, 0, 1)], dim=0)[None]
     net = gaussians.appearance_network
-    x = net.up3(net.up2(net.up1(net.relu(net.conv1(x)))))  # appearance_network.py:47-51, the module's own layers
+    x = _head(net, x)  # appearance_network.py:48-51: the module's own parameters and torch's convolutions
     up4_conv = getattr(net.up4, "conv", None)
     if up4_conv is not None and tuple(up4_conv.weight.shape) == (16, 8, 3, 3) and up4_conv.bias is not None and x.shape[1] == 32 and \
             getattr(getattr(net.up4, "pixel_shuffle", None), "upscale_factor", None) == 2:

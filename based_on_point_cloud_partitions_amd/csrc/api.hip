@@ -587,6 +587,26 @@ int gsr_appearance_up_backward(int feat_h, int feat_w, const float* x, const flo
     return check_hip("appearance_up_backward");
 }
 
+size_t gsr_bias_relu_scratch_bytes(int C) { return C > 0 ? gsr_bias_relu_scratch_bytes_impl(C) : 0; }
+
+int gsr_bias_relu_forward(int C, int64_t n, float* x, const float* bias, void* stream)
+{
+    if (C <= 0 || C > 65535 || n <= 0) return fail(-1, "bias_relu: C must be in 1..65535 and n positive");
+    if (!x || !bias) return fail(-1, "NULL required pointer");
+    gsr_launch_bias_relu_forward(C, (long long)n, x, bias, (hipStream_t)stream);
+    return check_hip("bias_relu_forward");
+}
+
+int gsr_bias_relu_backward(int C, int64_t n, const float* dL_dy, const float* y, float* dL_dx, float* dL_dbias, void* scratch,
+                           size_t scratch_bytes, void* stream)
+{
+    if (C <= 0 || C > 65535 || n <= 0) return fail(-1, "bias_relu: C must be in 1..65535 and n positive");
+    if (!dL_dy || !y || !dL_dx || !dL_dbias || !scratch) return fail(-1, "NULL required pointer");
+    if (scratch_bytes < gsr_bias_relu_scratch_bytes(C)) return fail(-3, "bias_relu scratch too small");
+    gsr_launch_bias_relu_backward(C, (long long)n, dL_dy, y, dL_dx, dL_dbias, (double*)scratch, (hipStream_t)stream);
+    return check_hip("bias_relu_backward");
+}
+
 size_t gsr_mse_scratch_bytes(int rows) { return rows > 0 ? gsr_mse_scratch_bytes_impl(rows) : 0; }
 
 int gsr_mse(int rows, int64_t n, const float* img1, const float* img2, float* out, void* scratch, size_t scratch_bytes, void* stream)

@@ -183,6 +183,9 @@ void gsr_launch_appearance_backward(int H, int W, int Hh, int Wh, const float* f
                                     int mask_relu, hipStream_t s);
 size_t gsr_appearance_up_scratch_bytes_impl();
 size_t gsr_mse_scratch_bytes_impl(int rows);
+size_t gsr_bias_relu_scratch_bytes_impl(int C);
+void gsr_launch_bias_relu_forward(int C, long long n, float* x, const float* bias, hipStream_t s);
+void gsr_launch_bias_relu_backward(int C, long long n, const float* g, const float* y, float* dz, float* db, double* partials, hipStream_t s);
 void gsr_launch_mse(int rows, long long n, const float* a, const float* b, float* out, double* partials, hipStream_t s);
 void gsr_launch_appearance_up_forward(int Hf, int Wf, const float* x, const float* w, const float* b, float* feat, hipStream_t s);
 void gsr_launch_appearance_up_backward(int Hf, int Wf, const float* x, const float* w, const float* dz, float* dx, float* dw, float* db,

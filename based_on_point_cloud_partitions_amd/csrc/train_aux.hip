@@ -81,6 +81,51 @@ __global__ void __launch_bounds__(256) compact_rows_kernel(int P, const uint8_t*
 // channel for a [3,H,W] image as train.py:227 passes it, per image for the [1,3,H,W] tensors of metrics.py:93).  Two fixed
 // order stages (256 partial sums per row in double, then their sum): bitwise reproducible.
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// Bias + ReLU after a convolution, and their backward with the bias gradient (the `+ bias`, nn.ReLU, threshold_backward and the
+// bias-gradient reduction that torch runs as four kernels around each Conv2d of the appearance head,
+// scene/ptgs/appearance_network.py:20-29,48): y [C][n] = max(x + b[c], 0) in place; dz = [y > 0] g, db[c] = sum_n dz[c][n]
+// (two fixed-order stages, sums in double).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BR_PARTS = 32;
+
+__global__ void __launch_bounds__(256) bias_relu_fwd_kernel(long long n, float* __restrict__ x, const float* __restrict__ bias)
+{
+    const int c = blockIdx.y;
+    const float b = bias[c];
+    float* p = x + (size_t)c * n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = fmaxf(p[i] + b, 0.0f);
+}
+
+__global__ void __launch_bounds__(256) bias_relu_bwd_kernel(long long n, const float* __restrict__ g, const float* __restrict__ y,
+                                                            float* __restrict__ dz, double* __restrict__ partials)
+{
+    __shared__ double s_w[4];
+    const int c = blockIdx.y, part = blockIdx.x;
+    const long long per = (n + BR_PARTS - 1) / BR_PARTS, lo = part * per, hi = lo + per < n ? lo + per : n;
+    const size_t base = (size_t)c * n;
+    double acc = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float v = y[base + i] > 0.0f ? g[base + i] : 0.0f;
+        dz[base + i] = v;
+        acc += (double)v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)c * BR_PARTS + part] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
+
+__global__ void __launch_bounds__(64) bias_relu_bwd_final_kernel(int C, const double* __restrict__ partials, float* __restrict__ db)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int p = 0; p < BR_PARTS; p++) acc += partials[(size_t)c * BR_PARTS + p];
+    db[c] = (float)acc;
+}
+
 constexpr int MSE_PARTS = 256;
 
 __global__ void __launch_bounds__(256) mse_partial_kernel(long long n, const float* __restrict__ a, const float* __restrict__ b,
@@ -148,5 +193,19 @@ void gsr_launch_mse(int rows, long long n, const float* a, const float* b, float
 {
     mse_partial_kernel<<<dim3(MSE_PARTS, rows), 256, 0, s>>>(n, a, b, partials);
     mse_final_kernel<<<rows, 256, 0, s>>>(n, partials, out);
+}
+
+size_t gsr_bias_relu_scratch_bytes_impl(int C) { return (size_t)C * BR_PARTS * sizeof(double); }
+
+void gsr_launch_bias_relu_forward(int C, long long n, float* x, const float* bias, hipStream_t s)
+{
+    const long long blocks = (n + 1023) / 1024;
+    bias_relu_fwd_kernel<<<dim3((unsigned)(blocks < 256 ? (blocks > 0 ? blocks : 1) : 256), C), 256, 0, s>>>(n, x, bias);
+}
+
+void gsr_launch_bias_relu_backward(int C, long long n, const float* g, const float* y, float* dz, float* db, double* partials, hipStream_t s)
+{
+    bias_relu_bwd_kernel<<<dim3(BR_PARTS, C), 256, 0, s>>>(n, g, y, dz, partials);
+    bias_relu_bwd_final_kernel<<<(C + 63) / 64, 64, 0, s>>>(C, partials, db);
 }
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 9
+#define GSR_ABI_VERSION 10
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -159,6 +159,15 @@ size_t gsr_appearance_up_scratch_bytes(int feat_h, int feat_w);
 int gsr_appearance_up_forward(int feat_h, int feat_w, const float* x, const float* weight, const float* bias, float* feat, void* stream);
 int gsr_appearance_up_backward(int feat_h, int feat_w, const float* x, const float* weight, const float* dz, float* dL_dx,
                                float* dL_dweight, float* dL_dbias, void* scratch, size_t scratch_bytes, void* stream);
+
+/* The `+ bias` and ReLU that follow each Conv2d of the appearance network's head (scene/ptgs/appearance_network.py:20-29,48), and
+ * their backward together with the bias gradient -- four torch kernels per layer otherwise.  x / y / dL_dy / dL_dx are [C][n]
+ * (n = H * W): forward y = max(x + bias[c], 0) IN PLACE on x; backward dL_dx = [y > 0] dL_dy, dL_dbias[c] = sum_n dL_dx[c][n]
+ * (fixed order, in double). */
+size_t gsr_bias_relu_scratch_bytes(int C);
+int gsr_bias_relu_forward(int C, int64_t n, float* x, const float* bias, void* stream);
+int gsr_bias_relu_backward(int C, int64_t n, const float* dL_dy, const float* y, float* dL_dx, float* dL_dbias, void* scratch,
+                           size_t scratch_bytes, void* stream);
 
 /* Evaluation metric of train.py:227 / metrics.py:93: mse of utils/image_utils.py:17-18,
  * out[r] = mean over n elements of (img1[r][i] - img2[r][i])^2 for r < rows; psnr = 20 log10(1 / sqrt(mse)) (:20-22) is left to

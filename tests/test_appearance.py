@@ -218,6 +218,26 @@ def test_decouple_appearance_matches_the_stock_torch_dataflow():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,H,W", [(256, 33, 60), (32, 264, 480), (5, 1, 1), (64, 7, 130)])
+def test_fused_bias_relu_matches_torch(C, H, W):
+    from based_on_point_cloud_partitions_amd.appearance import _BiasReLU
+
+    gen = torch.Generator().manual_seed(C + H)
+    x0 = torch.randn(1, C, H, W, generator=gen).cuda()
+    b0 = torch.randn(C, generator=gen).cuda()
+    g = torch.randn(1, C, H, W, generator=gen).cuda()
+    xa, ba = x0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    xb, bb = x0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    ya = _BiasReLU.apply(xa * 1.0, ba)  # (* 1.0: a non-leaf, as after a convolution -- the kernel writes in place)
+    yb = torch.relu(xb + bb[None, :, None, None])
+    assert torch.equal(ya, yb)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.equal(xa.grad, xb.grad)
+    assert (ba.grad - bb.grad).abs().max().item() <= 1e-5 * max(1.0, bb.grad.abs().max().item())
+
+
+@pytest.mark.gpu
 def test_appearance_tail_rejects_cpu_and_wrong_shapes():
     from based_on_point_cloud_partitions_amd import GsrError
     from based_on_point_cloud_partitions_amd.appearance import appearance_tail
