@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 10
+ABI_VERSION = 12
 
 _lib = None
 
@@ -26,7 +26,7 @@ PROTOTYPES = {
     "gsr_geometry_bytes": (c_size, [c_int]),
     "gsr_image_bytes": (c_size, [c_int, c_int]),
     "gsr_binning_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
-    "gsr_backward_scratch_bytes": (c_size, [c_i64]),
+    "gsr_backward_scratch_bytes": (c_size, [c_i64, c_int, c_int]),
     "gsr_forward_geometry": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
                                      c_void_p, c_size, ctypes.POINTER(c_i64), c_void_p]),
@@ -71,6 +71,8 @@ PROTOTYPES = {
     "gsr_knn_scratch_bytes": (c_size, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),
+    "gsr_debug_export_blocks": (c_int, [c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_set_variant": (None, [ctypes.c_char_p, c_int]),
     "gsr_profile_enable": (None, [c_int]),
     "gsr_profile_select": (None, [ctypes.c_uint32]),
     "gsr_profile_collect": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64), c_int]),
@@ -130,6 +132,11 @@ def profile_collect():
     cnt = (c_i64 * n)()
     check(load().gsr_profile_collect(ms, cnt, n), "gsr_profile_collect")
     return {STAGES[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+
+def set_variant(name, value):
+    """Overrides the experiment switch GSR_<name> for this process (tests / A-B runs)."""
+    load().gsr_set_variant(name.encode(), int(value))
 
 
 def check(status, what):

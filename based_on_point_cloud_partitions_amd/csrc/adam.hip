@@ -72,11 +72,14 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs args)
 
 int gsr_launch_adam(int n_tensors, const GsrAdamTensorHost* t, double beta1, double beta2, double eps, hipStream_t s)
 {
-    for (int first = 0; first < n_tensors; first += ADAM_MAX_TENSORS) {
+    // `k` runs over the input once: a chunk ends when ADAM_MAX_TENSORS non-empty tensors are packed, and the next chunk
+    // continues at the first entry not yet consumed (empty tensors -- e.g. features_rest at sh_degree 0 -- take no slot).
+    int k = 0;
+    while (k < n_tensors) {
         AdamArgs a;
         a.n_tensors = 0;
         int blocks = 0;
-        for (int k = first; k < n_tensors && a.n_tensors < ADAM_MAX_TENSORS; k++) {
+        for (; k < n_tensors && a.n_tensors < ADAM_MAX_TENSORS; k++) {
             if (t[k].n <= 0) continue;
             AdamTensor& d = a.t[a.n_tensors++];
             d.p = t[k].param; d.g = t[k].grad; d.m = t[k].exp_avg; d.v = t[k].exp_avg_sq; d.n = (long)t[k].n;

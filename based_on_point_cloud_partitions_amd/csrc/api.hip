@@ -132,23 +132,81 @@ __global__ void __launch_bounds__(256) export_geom_kernel(int P, const float* __
 
 }  // namespace
 
+// Experiment switches: GSR_<NAME> is read from the environment ONCE per name (first use) and cached, so launches from
+// several host threads never race on getenv and a switch cannot change between the stages of one step.  gsr_set_variant
+// (tests, A/B runs inside one process) overrides an entry.
+namespace {
+struct VariantEntry { char name[24]; bool set; int value; };
+VariantEntry g_variants[64];
+int g_n_variants = 0;
+std::mutex g_variant_mu;
+}  // namespace
+
 int gsr_variant(const char* name, int dflt)
 {
+    std::lock_guard<std::mutex> lk(g_variant_mu);
+    for (int i = 0; i < g_n_variants; i++)
+        if (strcmp(g_variants[i].name, name) == 0) return g_variants[i].set ? g_variants[i].value : dflt;
     char key[64];
     snprintf(key, sizeof(key), "GSR_%s", name);
     const char* v = getenv(key);
+    if (g_n_variants < 64 && strlen(name) < sizeof(g_variants[0].name)) {
+        VariantEntry& e = g_variants[g_n_variants++];
+        strcpy(e.name, name);
+        e.set = v != nullptr;
+        e.value = v ? atoi(v) : 0;
+    }
     return v ? atoi(v) : dflt;
 }
+
+static void gsr_variant_store(const char* name, int value)
+{
+    std::lock_guard<std::mutex> lk(g_variant_mu);
+    for (int i = 0; i < g_n_variants; i++)
+        if (strcmp(g_variants[i].name, name) == 0) { g_variants[i].set = true; g_variants[i].value = value; return; }
+}
+
+// The per-block lists + Gaussian-per-lane backward need the banded/tile binning (launch order) and the 8x8 wave layout.
+bool gsr_block_lists_enabled() { return gsr_variant("BLK", 1) && gsr_variant("BIN", 1) && gsr_variant("WAVE8X8", 1); }
 
 extern "C" {
 
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+void gsr_set_variant(const char* name, int value)
+{
+    if (!name) return;
+    gsr_variant(name, 0);  // make sure the entry exists
+    gsr_variant_store(name, value);
+}
 const char* gsr_last_error(void) { return g_err; }
 
 size_t gsr_geometry_bytes(int P) { return gsr_geom_layout(P).bytes; }
 size_t gsr_image_bytes(int W, int H) { return gsr_image_layout(W, H).bytes; }
 size_t gsr_binning_bytes(int64_t R, int P, int W, int H) { return gsr_bin_layout((long)R, P, W, H).bytes; }
-size_t gsr_backward_scratch_bytes(int64_t R) { return gsr_align((size_t)(R > 0 ? R : 1) * GSR_GROW_F * 4); }
+// Backward scratch.  Per-block lists (default): up to one 48-byte row per (instance, quadrant) pair -- only the pairs the
+// forward marked are ever written or read, the rest is address space --, the row numbering rowinfo[R + 1] and its scan
+// workspace.  Without them: one row per instance.
+struct BwdScratch { size_t rows, rowinfo, sums, offsets, total, queues, bytes; };
+static BwdScratch bwd_scratch_layout(int64_t R, int W, int H)
+{
+    BwdScratch L;
+    const size_t r = (size_t)(R > 0 ? R : 1);
+    size_t o = 0;
+    L.rows = o;
+    if (!gsr_block_lists_enabled()) { o = gsr_align(r * GSR_GROW_F * 4); L.rowinfo = L.sums = L.offsets = L.total = L.queues = o; L.bytes = o; return L; }
+    o = gsr_align(4 * r * GSR_GROW_F * 4);
+    const size_t nb = gsr_row_scan_blocks(R);
+    L.rowinfo = o; o = gsr_align(o + (r + 1) * 4);
+    L.sums = o; o = gsr_align(o + nb * 4);
+    L.offsets = o; o = gsr_align(o + nb * 4);
+    L.total = o; o = gsr_align(o + 16);
+    (void)W; (void)H;
+    L.queues = o; o = gsr_align(o + gsr_skew_queue_bytes());  // heads of the blend kernel's block queues
+    L.bytes = o;
+    return L;
+}
+size_t gsr_backward_scratch_bytes(int64_t R, int W, int H) { return bwd_scratch_layout(R, W, H).bytes; }
 
 // Phase 1 shared by gsr_forward_geometry, gsr_forward and gsr_forward_params: `a` carries the inputs, the outputs inside the
 // geometry buffer are filled in here.  launch_geometry enqueues the two kernels, wait_geometry returns R.
@@ -315,8 +373,11 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
     {
         StageTimer t(GSR_STAGE_RENDER_FWD, s);
         const uint32_t* order = (R > 0 && gsr_variant("BIN", 1)) ? (const uint32_t*)(b + B.order) : nullptr;
+        const bool lists = R > 0 && gsr_block_lists_enabled();
+        if (lists) hipMemsetAsync(b + B.bmask, 0, (size_t)R * 4, s);  // one byte per (instance slot, quadrant); the walk sets the used ones
         gsr_launch_render_forward(W, H, ranges, point_list, (const float*)(g + G.splat), background, (float*)(im + I.final_T),
-                                  (uint32_t*)(im + I.n_contrib), out_color, order, s);
+                                  (uint32_t*)(im + I.n_contrib), out_color, order, lists ? (uint2*)(b + B.blist) : nullptr,
+                                  lists ? (uint32_t*)(b + B.bcount) : nullptr, lists ? (uint8_t*)(b + B.bmask) : nullptr, s);
     }
     return check_hip("forward_render");
 }
@@ -403,12 +464,24 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     const BinLayout B = gsr_bin_layout((long)R, P, W, H);
     if (geom_bytes < G.bytes || image_bytes < I.bytes) return fail(-3, "state buffer too small");
     if (R > 0 && (!binning_buffer || binning_bytes < B.bytes)) return fail(-3, "binning buffer too small");
-    if (R > 0 && (!scratch || scratch_bytes < gsr_backward_scratch_bytes(R))) return fail(-3, "backward scratch too small");
+    if (R > 0 && (!scratch || scratch_bytes < gsr_backward_scratch_bytes(R, W, H))) return fail(-3, "backward scratch too small");
     const char* g = (const char*)geom_buffer;
     const char* b = (const char*)binning_buffer;
     const char* im = (const char*)image_buffer;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-    if (R > 0) {
+    const bool lists = gsr_block_lists_enabled();
+    const BwdScratch S = bwd_scratch_layout(R, W, H);
+    char* sc = (char*)scratch;
+    if (R > 0 && lists) {
+        // Gaussian-per-lane blend backward over the per-block lists the forward left in the binning buffer
+        StageTimer t(GSR_STAGE_RENDER_BWD, s);
+        gsr_launch_row_scan((uint32_t)R, (const uint8_t*)(b + B.bmask), (uint32_t*)(sc + S.sums), (uint32_t*)(sc + S.offsets),
+                            (uint32_t*)(sc + S.total), (uint32_t*)(sc + S.rowinfo), (uint32_t*)(sc + S.queues), s);
+        gsr_launch_render_backward_skew(W, H, (const uint32_t*)(b + B.order), (const uint32_t*)(im + I.ranges), (const uint2*)(b + B.blist),
+                                        (const uint32_t*)(b + B.bcount), (const uint32_t*)(sc + S.rowinfo), (const float*)(g + G.splat),
+                                        background, (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
+                                        (float*)(sc + S.rows), (uint32_t*)(sc + S.queues), s);
+    } else if (R > 0) {
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));
         const bool in_b = !gsr_variant("BIN", 1) && gsr_sort_result_in_b(end_bit);
         const uint32_t* point_list = (const uint32_t*)(b + (in_b ? B.vals_b : B.vals_a));
@@ -421,7 +494,8 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);
     a.tiles_touched = (const uint32_t*)(g + G.tiles_touched);
     a.point_offsets = (const uint32_t*)(g + G.point_offsets);
-    a.grad_rows = (const float*)scratch;
+    a.grad_rows = (const float*)(sc + S.rows);
+    a.rowinfo = (R > 0 && lists) ? (const uint32_t*)(sc + S.rowinfo) : nullptr;
     { StageTimer t(GSR_STAGE_GAUSS_BWD, s); gsr_launch_gaussian_backward(a, s); }
     return check_hip("backward");
 }
@@ -739,6 +813,22 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
         if (n_contrib) hipMemcpyAsync(n_contrib, im + I.n_contrib, N * 4, hipMemcpyDeviceToDevice, s);
     }
     return check_hip("debug_export");
+}
+
+int gsr_debug_export_blocks(int P, int64_t R, int W, int H, const void* binning_buffer, uint32_t* blist, uint32_t* bcount,
+                            uint8_t* bmask, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0 || R <= 0) return 0;
+    if (!binning_buffer) return fail(-1, "NULL required pointer");
+    if (!gsr_block_lists_enabled()) return fail(-2, "block lists are disabled (GSR_BLK=0)");
+    const BinLayout B = gsr_bin_layout((long)R, P, W, H);
+    const char* b = (const char*)binning_buffer;
+    const size_t T = (size_t)((W + GSR_TILE_X - 1) / GSR_TILE_X) * ((H + GSR_TILE_Y - 1) / GSR_TILE_Y);
+    if (blist) hipMemcpyAsync(blist, b + B.blist, (size_t)R * 4 * 8, hipMemcpyDeviceToDevice, s);
+    if (bcount) hipMemcpyAsync(bcount, b + B.bcount, T * 4 * 4, hipMemcpyDeviceToDevice, s);
+    if (bmask) hipMemcpyAsync(bmask, b + B.bmask, (size_t)R * 4, hipMemcpyDeviceToDevice, s);
+    return check_hip("debug_export_blocks");
 }
 
 void gsr_profile_enable(int on)

@@ -94,7 +94,10 @@ __global__ void __launch_bounds__(256) bias_relu_fwd_kernel(long long n, float* 
     const int c = blockIdx.y;
     const float b = bias[c];
     float* p = x + (size_t)c * n;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = fmaxf(p[i] + b, 0.0f);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = p[i] + b;
+        p[i] = v > 0.0f ? v : (v != v ? v : 0.0f);  // torch's ReLU: NaN stays NaN
+    }
 }
 
 __global__ void __launch_bounds__(256) bias_relu_bwd_kernel(long long n, const float* __restrict__ g, const float* __restrict__ y,
@@ -106,7 +109,8 @@ __global__ void __launch_bounds__(256) bias_relu_bwd_kernel(long long n, const f
     const size_t base = (size_t)c * n;
     double acc = 0.0;
     for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const float v = y[base + i] > 0.0f ? g[base + i] : 0.0f;
+        const float yv = y[base + i];
+        const float v = yv <= 0.0f ? 0.0f : g[base + i];  // threshold_backward: a NaN activation lets the gradient through
         dz[base + i] = v;
         acc += (double)v;
     }
@@ -174,10 +178,11 @@ void gsr_launch_compact_count(int P, const uint8_t* keep, uint32_t* block_sums, 
 void gsr_launch_compact_rows(int P, const uint8_t* keep, const uint32_t* block_offsets, int n_tensors, const GsrCompactTensorHost* t,
                              hipStream_t s)
 {
-    for (int first = 0; first < n_tensors; first += COMPACT_MAX_TENSORS) {
+    int k = 0;  // runs over the input once; empty descriptors take no slot of a chunk
+    while (k < n_tensors) {
         CompactArgs a;
         a.n_tensors = 0;
-        for (int k = first; k < n_tensors && a.n_tensors < COMPACT_MAX_TENSORS; k++) {
+        for (; k < n_tensors && a.n_tensors < COMPACT_MAX_TENSORS; k++) {
             if (t[k].row_floats <= 0) continue;
             a.t[a.n_tensors].src = t[k].src; a.t[a.n_tensors].dst = t[k].dst; a.t[a.n_tensors].row_floats = (int)t[k].row_floats;
             a.n_tensors++;

@@ -139,7 +139,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dsh = torch.empty((P, M, 3), **f)
         dL_dscales = torch.empty((P, 3), **f)
         dL_drotations = torch.empty((P, 4), **f)
-        scratch = torch.empty(lib.gsr_backward_scratch_bytes(int(R)) if R > 0 else 0, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(lib.gsr_backward_scratch_bytes(int(R), W, H) if R > 0 else 0, dtype=torch.uint8, device=dev)
         means3D_c = _prep(means3D, dev, "means3D")
         sh_c, colors_c = _prep(sh, dev, "sh"), _prep(colors, dev, "colors_precomp")
         scales_c, rot_c, cov_c = _prep(scales, dev, "scales"), _prep(rotations, dev, "rotations"), _prep(cov3D_precomp, dev, "cov3D_precomp")
@@ -308,4 +308,21 @@ def debug_export(P, R, W, H, geomBuffer, binningBuffer, imgBuffer):
                      "keys_sorted", "point_list", "ranges", "final_T", "n_contrib"]
             _lib.check(lib.gsr_debug_export(P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imgBuffer),
                                             *[_ptr(out[k]) for k in order], _stream(dev)), "gsr_debug_export")
+    return out
+
+
+def debug_export_blocks(P, R, W, H, binningBuffer):
+    """Copies the per-8x8-block lists the forward left for the backward (tests / inspection only): blist int32 [4R, 2]
+    ({Gaussian id, position in the tile's list}), bcount int32 [4T], bmask uint8 [4R]; layout in include/gsrast_mi355x.h."""
+    lib = _lib.load()
+    dev = binningBuffer.device
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    n = max(R, 1)
+    out = dict(blist=torch.zeros((4 * n, 2), dtype=torch.int32, device=dev)[:4 * R],
+               bcount=torch.zeros((4 * T,), dtype=torch.int32, device=dev),
+               bmask=torch.zeros((4 * n,), dtype=torch.uint8, device=dev)[:4 * R])
+    if P and R:
+        with torch.cuda.device(dev):
+            _lib.check(lib.gsr_debug_export_blocks(P, R, W, H, _ptr(binningBuffer), _ptr(out["blist"]), _ptr(out["bcount"]),
+                                                   _ptr(out["bmask"]), _stream(dev)), "gsr_debug_export_blocks")
     return out

@@ -101,7 +101,7 @@ def rasterize_gaussian_params_backward(background, xyz, radii, features_dc, feat
         dL_dopacity = torch.empty((P, 1), **f)
         dL_dscaling = torch.empty((P, 3), **f)
         dL_drotation = torch.empty((P, 4), **f)
-        scratch = torch.empty(lib.gsr_backward_scratch_bytes(int(R)) if R > 0 else 0, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(lib.gsr_backward_scratch_bytes(int(R), W, H) if R > 0 else 0, dtype=torch.uint8, device=dev)
         xyz_c = _prep(xyz, dev, "xyz")
         dc_c, rest_c = _prep(features_dc, dev, "features_dc"), _prep(features_rest, dev, "features_rest")
         sc_c, rot_c = _prep(scaling, dev, "scaling"), _prep(rotation, dev, "rotation")

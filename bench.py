@@ -287,6 +287,18 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
     return res
 
 
+def kernel_source_hash():
+    """Identifies the kernel build a measurement belongs to: sha1 over the HIP sources (they travel with the repo snapshot)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "based_on_point_cloud_partitions_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -438,9 +450,21 @@ def main():
             kernels.append({"kernel": name, "avg_ms": round(avg_ms, 4), "launches": n,
                             "algorithmic_MB": round(sb[name] / 1e6, 2),
                             "achieved_GBs": round(sb[name] / 1e9 / (avg_ms * 1e-3), 1)})
-        pmc = {}
+        # PMC figures (HBM bytes, VALU instruction counts) come from separate rocprofv3 --pmc passes recorded in
+        # profiles/pmc_traffic.json together with the workload and the kernel-source hash they were measured on; they are merged
+        # into this run's per-kernel lines only when both match, otherwise they are reported apart under `pmc_from_profile`.
+        workload = (f"{args.config}: one partition of {P} random-init Gaussians per GPU, {W}x{H}, SH degree 3, "
+                    f"{len(cams)} ring cameras, fixed N(0,1) dL/dcolor")
+        build = kernel_source_hash()
+        pmc, pmc_stale = {}, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            meta = pmc.pop("_meta", {})
+            if meta.get("workload") != workload or meta.get("build") != build:
+                pmc_stale = {"source": "profiles/pmc_traffic.json", "measured_on": meta,
+                             "hbm_bytes": {k: v.get("hbm_bytes") for k, v in pmc.items()},
+                             "valu_insts": {k: v.get("sq_insts_valu") for k, v in pmc.items() if "sq_insts_valu" in v}}
+                pmc = {}
         except Exception:
             pass
         for k in kernels:
@@ -464,12 +488,7 @@ def main():
                         "note": "dominant kernel by time; blend kernels are VALU/LDS-bound pair loops (DESIGN.md), so their HBM "
                                 "fraction is low by construction -- see roofline_kernels for the streaming stages and "
                                 "roofline_step for the whole step"}
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    roofline["traffic"] = json.load(open(pmc)).get(d["kernel"], {}).get("hbm_bytes")
-                except Exception:
-                    pass
+            roofline["traffic"] = pmc.get(d["kernel"], {}).get("hbm_bytes")
             for extra in ("valu_insts", "simd_cycles_per_valu_inst"):  # what actually bounds the blend kernels
                 if extra in d:
                     roofline[extra] = d[extra]
@@ -480,8 +499,8 @@ def main():
             "value": round(world * args.steps / elapsed, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: one partition of {P} random-init Gaussians per GPU, {W}x{H}, SH degree 3, "
-                                   f"{len(cams)} ring cameras, fixed N(0,1) dL/dcolor", "gaussians_per_gpu": P,
+            "build": build,
+            "config": {"workload": workload, "gaussians_per_gpu": P,
                        "image": [W, H], "sh_degree": 3, "parallelism": f"{world} independent partition(s), 1 per GPU"},
             "workload_stats": {"P": P, "V_mean": round(V, 1), "R_mean": round(R, 1), "N": N, "key_bits": key_bits,
                                "tile_list_mean": round(float(np.mean([u["tile_mean"] for u in used])), 1),
@@ -497,6 +516,8 @@ def main():
                               "frac": round(step_bytes / 1e9 / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 4)},
             "roofline_kernels": kernels,
         }
+        if pmc_stale is not None:
+            out["pmc_from_profile"] = pmc_stale
         if full is not None:
             out["full_step"] = full
         if world == 1 and not args.no_cpu_baseline:

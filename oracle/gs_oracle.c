@@ -480,6 +480,38 @@ void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* po
     }
 }
 
+/* Per-8x8-block work lists of the backward (no reference counterpart: the reference's backward re-walks whole tile lists,
+ * backward.cu:470-482; this restates which (list entry, 8x8 block) pairs it finds work for).  flags[k - ranges[0]] gets bit
+ * q = 2*(ly/8) + lx/8 set iff list entry k is BLENDED into at least one pixel of quadrant q of its tile, with the forward's
+ * own predicates (forward.cu:332-357: power <= 0, alpha >= 1/255, pixel not yet done and not saturating at this entry). */
+void orc_block_flags(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                     const float* conic_opacity, /* out, one byte per list entry */ uint8_t* flags)
+{
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int ty = tile / gx, tx = tile % gx;
+        uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (uint32_t k = r0; k < r1; k++) flags[k] = 0;
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (px >= W || py >= H) continue;
+                float T = 1.0f;
+                for (uint32_t k = r0; k < r1; k++) {
+                    uint32_t id = point_list[k];
+                    float dx, dy, G, alpha;
+                    if (!blend_pair(means2D + 2 * (size_t)id, conic_opacity + 4 * (size_t)id, (float)px, (float)py, &dx, &dy, &G, &alpha))
+                        continue;
+                    float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) break;
+                    T = test_T;
+                    flags[k] |= (uint8_t)(1u << (2 * (ly / 8) + lx / 8));
+                }
+            }
+    }
+}
+
 /* K8 renderCUDA backward, backward.cu:399-557.  The reference accumulates the 9
  * per-Gaussian sums with float atomicAdd in nondeterministic order; the oracle
  * computes every per-pair term in fp32 exactly as typed and accumulates the sums

@@ -129,6 +129,18 @@ def forward(means3D, opacities, *, shs=None, colors_precomp=None, scales=None, r
     return st
 
 
+def block_flags(st):
+    """uint8 per list entry (aligned with st["point_list"]): bit q set iff the entry is blended into a pixel of quadrant q
+    (q = 2 * (y half) + (x half)) of its 16x16 tile -- the per-8x8-block work lists of the backward blend."""
+    L = lib()
+    R = st["num_rendered"]
+    flags = np.zeros(max(R, 1), np.uint8)
+    if R > 0:
+        L.orc_block_flags(ctypes.c_int(st["W"]), ctypes.c_int(st["H"]), _p(st["ranges"], _u32), _p(st["point_list"], _u32),
+                          _p(st["means2D"], _f), _p(st["conic_opacity"], _f), _p(flags, _u8))
+    return flags[:R]
+
+
 def backward(st, dL_dpix):
     """Full backward (K8..K10) for a state returned by forward()."""
     L = lib()

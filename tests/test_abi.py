@@ -36,7 +36,7 @@ def test_size_queries():
     lib = _lib.load()
     assert lib.gsr_geometry_bytes(500000) >= 500000 * (48 + 24 + 3 + 4 + 4)
     assert lib.gsr_binning_bytes(1000, 100, 64, 64) >= 1000 * 24
-    assert lib.gsr_backward_scratch_bytes(1000) >= 48000
+    assert lib.gsr_backward_scratch_bytes(1000, 64, 64) >= 48000
     assert lib.gsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 8
     assert lib.gsr_knn_scratch_bytes(1000) > 0 and lib.gsr_sort_scratch_bytes(1000) > 0
 

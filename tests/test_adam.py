@@ -192,3 +192,34 @@ def test_hip_adam_config2_sized_model():
         oracle.adam_step(pv.reshape(-1), g.numpy().reshape(-1), m, v, lr, 0.9, 0.999, 1e-15, 1)
         assert np.array_equal(p.detach().cpu().numpy(), pv), name
         assert np.array_equal(opt.state[p]["exp_avg_sq"].cpu().numpy().reshape(-1), v), name
+
+
+@pytest.mark.gpu
+def test_hip_adam_more_than_sixteen_tensors_with_an_empty_one():
+    """The reference optimizer with sh_degree = 0 and the appearance network: 6 Gaussian groups (features_rest is [P,0,3], its
+    gradient an EMPTY tensor, not None) + the embeddings + 14 network parameters = 21 tensors, more than one launch's table
+    (16).  Every tensor must get exactly one Adam step per iteration (a chunk used to restart on an entry already consumed)."""
+    from based_on_point_cloud_partitions_amd.optim import Adam
+
+    gen = torch.Generator().manual_seed(17)
+    shapes = [(257, 3), (257, 1, 3), (257, 0, 3), (257, 1), (257, 3), (257, 4), (40, 64)] + [(5 + k, 3 + (k % 4)) for k in range(14)]
+    assert len(shapes) == 21
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(100 + i)).cuda()) for i, s in enumerate(shapes)]
+    ps, qs = mk(), mk()
+    groups = lambda xs: [{"params": [p], "lr": 1e-3 * (1 + i % 5), "name": "t%d" % i} for i, p in enumerate(xs)]
+    opt = Adam(groups(ps), lr=0.0, eps=1e-15)
+    ref = torch.optim.Adam(groups(qs), lr=0.0, eps=1e-15, foreach=False)
+    for step in range(1, 5):
+        for p, q in zip(ps, qs):
+            g = torch.randn(p.shape, generator=gen) * 0.1
+            p.grad = g.cuda()
+            q.grad = g.cuda()
+        opt.step()
+        ref.step()
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            if p.numel() == 0:
+                continue
+            assert int(opt.state[p]["step"]) == step
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg="tensor %d step %d" % (i, step))
+            np.testing.assert_allclose(opt.state[p]["exp_avg"].cpu().numpy(), ref.state[q]["exp_avg"].cpu().numpy(), rtol=1e-6, atol=1e-9,
+                                       err_msg="exp_avg of tensor %d step %d" % (i, step))

@@ -11,6 +11,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
     float a = threadIdx.x * 1.0f, b = a + 1.f, c = a + 2.f, d = a + 3.f, e = a + 4.f, f = a + 5.f, g = a + 6.f, h = a + 7.f;
     unsigned long long m = 0xAAAAAAAAAAAAAAAAull;
     int mi = 0;
+    unsigned long long dd0 = threadIdx.x, dd1 = threadIdx.x + 7;
+    uint32_t mi0 = threadIdx.x, mi1 = threadIdx.x * 3;
     for (int i = 0; i < iters; i++) {
         if (KIND == 0) {
             asm volatile(REP16("v_add_f32 %0, %0, %1\n v_add_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_add_f32 %3, %3, %0\n")
@@ -163,11 +165,43 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
             asm volatile(REP16("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\nv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\ns_nop 0\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         } else if (KIND == 46) {
             asm volatile(REP16("v_rcp_f32 %0, %0\n s_nop 0\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 48) {
+            asm volatile(REP16("v_mov_b32_dpp %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+                               "v_mov_b32_dpp %2, %3 wave_ror:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 wave_ror:1 row_mask:0xf bank_mask:0xf\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 49) {
+            asm volatile(REP16("v_cndmask_b32_dpp %0, %1, %2, vcc wave_ror:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %1, %2, %3, vcc wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+                               "v_cndmask_b32_dpp %2, %3, %0, vcc wave_ror:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %3, %0, %1, vcc wave_ror:1 row_mask:0xf bank_mask:0xf\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");
+        } else if (KIND == 50) {
+            asm volatile(REP16("v_cndmask_b32_dpp %0, %1, %2, vcc row_ror:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %1, %2, %3, vcc row_ror:1 row_mask:0xf bank_mask:0xf\n"
+                               "v_cndmask_b32_dpp %2, %3, %0, vcc row_ror:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %3, %0, %1, vcc row_ror:1 row_mask:0xf bank_mask:0xf\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");
+        } else if (KIND == 51) {
+            asm volatile(REP16("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                               "v_mov_b32_dpp %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if (KIND == 52) {
+            asm volatile(REP16("v_mad_u64_u32 %0, %4, %1, 48, %0\n v_mad_u64_u32 %2, %4, %3, 48, %2\n v_mad_u64_u32 %0, %4, %1, 48, %0\n v_mad_u64_u32 %2, %4, %3, 48, %2\n")
+                         : "+v"(dd0), "+v"(mi0), "+v"(dd1), "+v"(mi1), "+s"(m));
+        } else if (KIND == 53) {
+            // single active lane: one wave-instruction costs the same issue time as with 64 lanes?
+            asm volatile("s_mov_b64 %4, exec\n s_mov_b64 exec, 1\n" REP16("v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n v_mov_b32 %2, 0\n v_mov_b32 %3, 0\n") "s_mov_b64 exec, %4\n"
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+s"(m));
+        } else if (KIND == 54) {
+            asm volatile(REP16("v_mov_b64 %0, 0\n v_mov_b64 %1, 0\n v_mov_b64 %0, 0\n v_mov_b64 %1, 0\n")
+                         : "+v"(dd0), "+v"(dd1));
+        } else if (KIND == 55) {
+            asm volatile(REP16("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0\n v_pk_fma_f32 %0, %0, %1, %0\n v_pk_add_f32 %1, %1, %0\n")
+                         : "+v"(dd0), "+v"(dd1));
+        } else if (KIND == 56) {
+            asm volatile(REP16("v_exp_f32 %0, %0\n v_mul_f32 %1, %1, %2\n v_rcp_f32 %2, %2\n v_mul_f32 %3, %3, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         } else if (KIND == 47) {
             asm volatile(REP16("v_exp_f32 %0, %0\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\nv_add_f32 %1, %1, %2\nv_add_f32 %2, %2, %3\nv_add_f32 %3, %3, %1\nv_add_f32 %1, %1, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + e + f + g + h + (float)mi + (float)(m & 1);
+    out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + e + f + g + h + (float)mi + (float)(m & 1) + (float)(dd0 + dd1) + (float)(mi0 + mi1);
 }
 
 template <int KIND>
@@ -193,7 +227,16 @@ int main()
 {
     float* out;
     hipMalloc(&out, 8192 * 256 * 4);
-    for (int wgs : {1536}) {
+    for (int wgs : {1024, 1536}) {
+        run<48>("v_mov_b32_dpp wave_ror:1", out, wgs);
+        run<49>("v_cndmask_b32_dpp wave_ror:1", out, wgs);
+        run<50>("v_cndmask_b32_dpp row_ror:1", out, wgs);
+        run<51>("v_mov_b32_dpp wave_shr:1", out, wgs);
+        run<52>("v_mad_u64_u32", out, wgs);
+        run<53>("v_mov_b32, one lane active", out, wgs);
+        run<54>("v_mov_b64", out, wgs);
+        run<55>("v_pk_mul/fma/add_f32", out, wgs);
+        run<56>("exp, mul, rcp, mul", out, wgs);
         run<0>("v_add_f32", out, wgs);
         run<7>("v_fma_f32", out, wgs);
         run<5>("v_cndmask_b32 (sgpr mask)", out, wgs);
