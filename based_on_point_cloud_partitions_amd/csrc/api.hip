@@ -167,7 +167,9 @@ static void gsr_variant_store(const char* name, int value)
 }
 
 // The per-block lists + Gaussian-per-lane backward need the banded/tile binning (launch order) and the 8x8 wave layout.
-bool gsr_block_lists_enabled() { return gsr_variant("BLK", 1) && gsr_variant("BIN", 1) && gsr_variant("WAVE8X8", 1); }
+// Off by default: measured on config 2 the per-block lists cost the forward 0.04 ms and the Gaussian-per-lane backward is no
+// faster than the pixel-per-lane kernel (profiles/README.md, round 2); kept as a tested alternative (GSR_BLK=1).
+bool gsr_block_lists_enabled() { return gsr_variant("BLK", 0) && gsr_variant("BIN", 1) && gsr_variant("WAVE8X8", 1); }
 
 extern "C" {
 

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) render_backward_skew_kernel(int W, int H,
     // A workgroup is four INDEPENDENT waves (no barrier, nothing shared): its only purpose is to put one wave on each SIMD of a CU
     // -- single-wave workgroups were placed unevenly and the waves of crowded SIMDs ran up to 1.7x longer than the rest.
     __shared__ float4 s_pix_all[4][PIX_SLOTS * 128];  // per wave and slot: 64 x {px, py, last contributor (uint bits), T_final | dL0, dL1, dL2, bg . dL}
-    __shared__ float4 s_sa_all[4][64], s_sb_all[4][64], s_sc_all[4][64];  // staged items: {mx, my, cx, cy | cz, opacity, -, list position | r, g, b, row}
+    __shared__ float4 s_sa_all[4][64], s_sb_all[4][64], s_sc_all[4][64];  // staged items: {mx, my, cx, cy | cz, opacity, r, g | b, row, list position, -}
     const int lane = threadIdx.x & 63;
     const int wv = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: everything derived from it stays in SGPRs
     const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)wv;
@@ -246,62 +246,89 @@ __global__ void __launch_bounds__(256) render_backward_skew_kernel(int W, int H,
     };
 
     // ---- gathering an epoch's items (one per lane) ----
-    struct Held { float4 a, b, c; } held;                 // the lane's item of the NEXT epoch, until its stage slot is free
-    float4 pixh0 = make_float4(0.f, 0.f, 0.f, 0.f), pixh1 = pixh0;  // pixel constants of the next epoch's new block (lane = pixel)
-    auto null_item = [&]() {
-        held.a = make_float4(0.f, 0.f, 1.f, 0.f);
-        held.b = make_float4(1.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));   // opacity 0, behind every last contributor: never blends
-        held.c = make_float4(0.f, 0.f, 0.f, __uint_as_float(NO_ROW));
-    };
-    auto gather_items = [&](const Plan& p) {
-        null_item();
-        const bool isA = lane < p.nA, isB = !isA && lane < p.nA + p.nB;
-        if (isA || isB) {
-            const BlockRef& b = isA ? p.A : p.B;
-            const uint32_t pos = isA ? p.posA - (uint32_t)lane : p.posB - (uint32_t)(lane - p.nA);
-            const unsigned long long li = (((unsigned long long)(isA ? p.A.list_hi : p.B.list_hi)) << 32 | (isA ? p.A.list_lo : p.B.list_lo)) + pos;
-            const uint2 it = blist[li];
-            const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)it.x * GSR_SPLAT_F);
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-            const uint32_t tile = isA ? p.A.tile : p.B.tile, q = isA ? p.A.q : p.B.q;
-            const uint32_t bx = tile % (uint32_t)gx, by = tile / (uint32_t)gx;
-            uint32_t mnx, mny, mxx, mxy;
-            gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
-            const uint32_t slot = __float_as_uint(q2.w) + (by - mny) * (mxx - mnx) + (bx - mnx);
-            const uint32_t ri = rowinfo[slot];
-            const uint32_t row = (ri >> 4) + (uint32_t)__popc(ri & ((1u << q) - 1u));
-            held.a = q0;
-            held.b = make_float4(q1.x, q1.y, 0.f, __uint_as_float(it.y));
-            held.c = make_float4(q1.z, q1.w, q2.x, __uint_as_float(row));
-            (void)b;
+    // Three dependent loads (list entry -> 48-byte splat record -> row numbering) plus the new block's pixel constants.  They are
+    // issued one stage per 8-step group (gather_stage 0..3) and each result is first touched a group later: a load has ~2000
+    // cycles to land, and the registers it lands in stay live in between, so the steps never wait on them.
+    // the lane's item of the NEXT epoch, until its stage slot is free: {mx, my, cx, cy | cz, opacity, r, g | b, row, list position, -}
+    struct Held { float4 a, b, c; } held;
+    const float4 pixh0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 g_it = make_uint2(0u, 0u);                      // in flight: list entry {Gaussian id, list position}
+    float4 g_q2 = pixh0;                                  // in flight: third quarter of the splat record (the first two land in held.a / held.b)
+    uint32_t g_ri = 0, g_q = 0;                           // in flight: row numbering word; the item's quadrant
+    bool g_valid = false;
+    float g_Tf = 0.f, g_d0 = 0.f, g_d1 = 0.f, g_d2 = 0.f; // in flight: the new block's pixel constants
+    uint32_t g_lc = 0, g_px = 0, g_py = 0;
+    auto gather_stage = [&](const Plan& p, int stage) {
+        if (stage == 0) {
+            const bool isA = lane < p.nA, isB = !isA && lane < p.nA + p.nB;
+            g_valid = isA || isB;
+            g_q = isA ? p.A.q : p.B.q;
+            if (g_valid) {
+                const uint32_t pos = isA ? p.posA - (uint32_t)lane : p.posB - (uint32_t)(lane - p.nA);
+                const unsigned long long li = (((unsigned long long)(isA ? p.A.list_hi : p.B.list_hi)) << 32 | (isA ? p.A.list_lo : p.B.list_lo)) + pos;
+                g_it = blist[li];
+            }
+            if (p.nB != 0) {  // pixel constants of the block that starts in this epoch (lane = pixel)
+                const uint32_t tile = p.B.tile, q = p.B.q;
+                const uint32_t bx = tile % (uint32_t)gx, by = tile / (uint32_t)gx;
+                g_px = bx * GSR_TILE_X + (q & 1u) * 8u + ((uint32_t)lane & 7u);
+                g_py = by * GSR_TILE_Y + (q >> 1) * 8u + ((uint32_t)lane >> 3);
+                g_Tf = 0.f; g_d0 = 0.f; g_d1 = 0.f; g_d2 = 0.f; g_lc = 0;
+                if (g_px < (uint32_t)W && g_py < (uint32_t)H) {
+                    const size_t pid = (size_t)W * g_py + g_px;
+                    g_Tf = final_Ts[pid]; g_lc = n_contrib[pid];
+                    g_d0 = dL_dpixels[pid]; g_d1 = dL_dpixels[plane + pid]; g_d2 = dL_dpixels[2 * plane + pid];
+                }
+            }
+        } else if (stage == 1) {
+            if (g_valid) {
+                const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)g_it.x * GSR_SPLAT_F);
+                held.a = rec[0]; held.b = rec[1]; g_q2 = rec[2];
+            }
+        } else if (stage == 2) {
+            if (g_valid) {
+                const bool isA = lane < p.nA;
+                const uint32_t tile = isA ? p.A.tile : p.B.tile;
+                const uint32_t bx = tile % (uint32_t)gx, by = tile / (uint32_t)gx;
+                uint32_t mnx, mny, mxx, mxy;
+                gsr_get_rect(held.a.x, held.a.y, __float_as_int(g_q2.z), gx, gy, mnx, mny, mxx, mxy);
+                g_ri = rowinfo[__float_as_uint(g_q2.w) + (by - mny) * (mxx - mnx) + (bx - mnx)];
+            }
+        } else {
+            if (g_valid) {
+                const uint32_t row = (g_ri >> 4) + (uint32_t)__popc(g_ri & ((1u << g_q) - 1u));
+                held.c = make_float4(g_q2.x, __uint_as_float(row), __uint_as_float(g_it.y), 0.f);
+            } else {  // idle lane: opacity 0 and behind every last contributor -- never blends; no row
+                held.a = make_float4(0.f, 0.f, 1.f, 0.f);
+                held.b = make_float4(1.f, 0.f, 0.f, 0.f);
+                held.c = make_float4(0.f, __uint_as_float(NO_ROW), __uint_as_float(0xFFFFFFFFu), 0.f);
+            }
         }
-    };
-    auto gather_pixels = [&](const Plan& p) {
-        if (p.nB == 0) return;
-        const uint32_t tile = p.B.tile, q = p.B.q;
-        const uint32_t bx = tile % (uint32_t)gx, by = tile / (uint32_t)gx;
-        const uint32_t pix_x = bx * GSR_TILE_X + (q & 1u) * 8u + ((uint32_t)lane & 7u);
-        const uint32_t pix_y = by * GSR_TILE_Y + (q >> 1) * 8u + ((uint32_t)lane >> 3);
-        const bool inside = pix_x < (uint32_t)W && pix_y < (uint32_t)H;
-        float Tf = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
-        uint32_t lc = 0;
-        if (inside) {
-            const size_t pid = (size_t)W * pix_y + pix_x;
-            Tf = final_Ts[pid]; lc = n_contrib[pid];
-            d0 = dL_dpixels[pid]; d1 = dL_dpixels[plane + pid]; d2 = dL_dpixels[2 * plane + pid];
-        }
-        const float bg_dot = ((0.f + bg0 * d0) + bg1 * d1) + bg2 * d2;
-        pixh0 = make_float4((float)pix_x, (float)pix_y, __uint_as_float(lc), Tf);
-        pixh1 = make_float4(d0, d1, d2, bg_dot);
     };
     auto commit_items = [&](bool low_half) {
         if ((lane < 32) == low_half) { s_sa[lane] = held.a; s_sb[lane] = held.b; s_sc[lane] = held.c; }
     };
+    // finished rows wait in the lanes' row buffers; the 32 lanes of a half store theirs together once all of them have switched
+    float rb0 = 0.f, rb1 = 0.f, rb2 = 0.f, rb3 = 0.f, rb4 = 0.f, rb5 = 0.f, rb6 = 0.f, rb7 = 0.f, rb8 = 0.f;
+    uint32_t rb_row = NO_ROW;
+    auto flush_rows = [&](bool low_half) {
+        if ((lane < 32) == low_half && rb_row != NO_ROW) {
+            float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)rb_row * GSR_GROW_F);
+            o[0] = make_float4(rb1, rb2, rb3, rb4);
+            o[1] = make_float4(rb5, rb0, rb6, rb7);
+            reinterpret_cast<float*>(o)[8] = rb8;  // the row's last three floats are never read
+        }
+    };
+    // a group later (the stores have read their data by then, so nothing waits on them): the buffers go back to zero
+    auto flush_done = [&](bool low_half) {
+        if ((lane < 32) == low_half) { rb0 = 0.f; rb1 = 0.f; rb2 = 0.f; rb3 = 0.f; rb4 = 0.f; rb5 = 0.f; rb6 = 0.f; rb7 = 0.f; rb8 = 0.f; rb_row = NO_ROW; }
+    };
     auto commit_pixels = [&](const Plan& p) {
         if (p.nB == 0) return;
         float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(s_pix) + p.pixB);
-        dst[2 * lane] = pixh0;
-        dst[2 * lane + 1] = pixh1;
+        const float bg_dot = ((0.f + bg0 * g_d0) + bg1 * g_d1) + bg2 * g_d2;
+        dst[2 * lane] = make_float4((float)g_px, (float)g_py, __uint_as_float(g_lc), g_Tf);
+        dst[2 * lane + 1] = make_float4(g_d0, g_d1, g_d2, bg_dot);
     };
 
     // ---- the lanes' running state ----
@@ -315,8 +342,7 @@ __global__ void __launch_bounds__(256) render_backward_skew_kernel(int W, int H,
     Plan planc, plann;   // current epoch's plan, next epoch's plan
     plan_epoch(planc);
     if (planc.nA + planc.nB == 0) return;  // nothing for this wave
-    gather_items(planc);
-    gather_pixels(planc);
+    for (int st = 0; st < 4; st++) gather_stage(planc, st);
     commit_items(true);
     commit_items(false);
     commit_pixels(planc);
@@ -335,32 +361,43 @@ __global__ void __launch_bounds__(256) render_backward_skew_kernel(int W, int H,
         last_items = planc.nA + planc.nB;
         for (int c = 0; c < groups; c++) {
             if (c == 0) {
+                flush_done(false);    // (the rows of lanes 32..63 were stored at the end of the previous epoch)
                 plan_epoch(plann);
-                gather_items(plann);
-                gather_pixels(plann);
+                gather_stage(plann, 0);
+            } else if (c < 4) {
+                gather_stage(plann, c);
             } else if (c == 4) {
-                commit_items(true);   // stage slots 0..31 were all picked up during steps 0..31
+                flush_rows(true);     // lanes 0..31 have all switched (steps 0..31): their stage slots are free, their rows complete
+                commit_items(true);
+            } else if (c == 5) {
+                flush_done(true);
             }
-            for (int i = 0; i < 8; i++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {  // unrolled: a taken branch costs a wave ~40 cycles, the step body has none on its common path
                 const int k = 8 * c + i;
                 // lane k moves on to its item of this epoch: store the finished item's row, pick up the new one
                 if (!(XV & 2) && lane == k) {
-                    if (!(XV & 1) && row != NO_ROW) {
-                        float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
-                        o[0] = make_float4(acc1, acc2, acc3, acc4);
-                        o[1] = make_float4(acc5, acc0, acc6, acc7);
-                        reinterpret_cast<float*>(o)[8] = acc8;  // the row's last three floats are never read
-                    }
                     const float4 a = s_sa[k], b = s_sb[k], cc = s_sc[k];
+                    // the finished sums move to the lane's row buffer, which holds zeros (flush_done): one v_swap_b32 per value both
+                    // saves the row and clears the accumulator.  The row leaves for HBM with those of 31 other lanes (flush_rows).
+                    // (A store straight from the accumulators must be waited for before they can be cleared -- one memory round trip
+                    // per step; parking the row in LDS costs the LDS store path as much as a full-wave write, every step.)
+                    if (!(XV & 1)) {
+                        asm volatile("v_swap_b32 %0, %9\n v_swap_b32 %1, %10\n v_swap_b32 %2, %11\n v_swap_b32 %3, %12\n v_swap_b32 %4, %13\n"
+                                     "v_swap_b32 %5, %14\n v_swap_b32 %6, %15\n v_swap_b32 %7, %16\n v_swap_b32 %8, %17\n"
+                                     : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4), "+v"(acc5), "+v"(acc6), "+v"(acc7), "+v"(acc8),
+                                       "+v"(rb0), "+v"(rb1), "+v"(rb2), "+v"(rb3), "+v"(rb4), "+v"(rb5), "+v"(rb6), "+v"(rb7), "+v"(rb8));
+                        rb_row = row;
+                    } else { acc0 = 0.f; acc1 = 0.f; acc2 = 0.f; acc3 = 0.f; acc4 = 0.f; acc5 = 0.f; acc6 = 0.f; acc7 = 0.f; acc8 = 0.f; }
                     mx = a.x; my = a.y; cx = a.z; cy = a.w;
-                    cz = b.x; op = b.y; kidx = __float_as_uint(b.w);
-                    cr = cc.x; cg = cc.y; cb = cc.z; row = __float_as_uint(cc.w);
+                    cz = b.x; op = b.y; cr = b.z; cg = b.w;
+                    cb = cc.x; row = __float_as_uint(cc.y); kidx = __float_as_uint(cc.z);
                     pa = k < planc.nA ? planc.pixA : planc.pixB;
-                    acc0 = 0.f; acc1 = 0.f; acc2 = 0.f; acc3 = 0.f; acc4 = 0.f; acc5 = 0.f; acc6 = 0.f; acc7 = 0.f; acc8 = 0.f;
                 }
                 {
                     const unsigned long long bit = 1ull << k;
-                    first_mask = (planc.nB > 0 && k == planc.nA) ? (first_mask | bit) : (first_mask & ~bit);
+                    const unsigned long long set = (planc.nB > 0 && k == planc.nA) ? bit : 0ull;  // s_cselect, no branch
+                    first_mask = (first_mask & ~bit) | set;
                 }
                 // this step's pixel
                 float4 p0, p1;
@@ -378,7 +415,7 @@ __global__ void __launch_bounds__(256) render_backward_skew_kernel(int W, int H,
                 float alpha = fminf(0.99f, op * G);
                 // entries at or behind the pixel's last contributor were never blended into it (backward.cu:480-482)
                 const unsigned long long m_pre = __builtin_amdgcn_ballot_w64(kidx < __float_as_uint(p0.z)) & __builtin_amdgcn_ballot_w64(power <= 0.0f);
-                if (FAST_EXP && !(XV & 4) && (m_pre & __builtin_amdgcn_ballot_w64(fabsf(alpha - 1.0f / 255.0f) < 3e-8f)) != 0ull) {
+                if (FAST_EXP && !(XV & 4) && __builtin_expect((m_pre & __builtin_amdgcn_ballot_w64(fabsf(alpha - 1.0f / 255.0f) < 3e-8f)) != 0ull, 0)) {
                     G = gsr_expf(fminf(power, 0.0f));  // the forward's exp for the decision (see render_backward.hip)
                     alpha = fminf(0.99f, op * G);
                 }
@@ -418,6 +455,11 @@ __global__ void __launch_bounds__(256) render_backward_skew_kernel(int W, int H,
             }
         }
         // epoch boundary: stage slots 32..63 and the new block's pixel slot are free now
+        if (groups > 4) flush_rows(false);
+        if (!real) {  // that was the flushing epoch: whatever it parked in the low half (all of it if it was short) leaves now
+            if (groups <= 4) { flush_rows(true); flush_rows(false); }
+            break;
+        }
         commit_items(false);
         commit_pixels(plann);
         planc = plann;

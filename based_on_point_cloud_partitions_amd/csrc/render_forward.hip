@@ -104,6 +104,47 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             s_b[kept + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
         }
         __syncthreads();
+        if (!LISTS) {
+            if (!wave_done) {
+                for (int j0 = 0; j0 < kept; j0 += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + u;
+                        const float4 a = s_a[j];
+                        const float4 b = s_b[j];
+                        const float dx = a.x - px, dy = a.y - pixf_y;
+                        // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
+                        const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
+                        const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
+                        // one compare (parked pixels and padding entries give -inf / NaN / pthr = inf and fail it); power > 0 is
+                        // left to the exact path
+                        const bool maybe = power >= b.z;
+                        if (gsr_any(maybe)) {  // wave-uniform; rare relative to the skip
+                            if (maybe && px != PARKED && power <= 0.0f) {
+                                const float alpha = fminf(0.99f, b.y * gsr_expf_inrange(power));
+                                if (alpha >= 1.0f / 255.0f) {
+                                    const float test_T = T * (1.0f - alpha);
+                                    if (test_T < 0.0001f) {
+                                        px = PARKED;  // done
+                                    } else {
+                                        const float4 c = s_c[j];
+                                        // CONTRACT-FMA: C += (f*alpha)*T
+                                        C0 = __builtin_fmaf(c.x * alpha, T, C0);
+                                        C1 = __builtin_fmaf(c.y * alpha, T, C1);
+                                        C2 = __builtin_fmaf(c.z * alpha, T, C2);
+                                        T = test_T;
+                                        last_contributor = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (!gsr_any(px != PARKED)) { wave_done = true; break; }
+                }
+            }
+            continue;
+        }
+        // LISTS: the same walk, 64 entries at a time with one bit per entry for the block's list
         if (!wave_done) {
             for (int jb = 0; jb < kept && !wave_done; jb += 64) {  // 64 entries at a time: one bit per entry for the block list
                 unsigned long long mbits = 0ull;

@@ -12,6 +12,16 @@ from helpers import hip_forward_raw, oracle_forward, scene
 from oracle import oracle
 
 
+@pytest.fixture
+def block_lists_on():
+    """The per-block lists + Gaussian-per-lane backward are an alternative (GSR_BLK, off by default): switch them on for a test."""
+    from based_on_point_cloud_partitions_amd import _lib
+
+    _lib.set_variant("BLK", 1)
+    yield
+    _lib.set_variant("BLK", 0)
+
+
 def _expected_lists(st):
     """-> {(tile, q): [(gaussian id, position in the tile list), ...]} from the oracle's flags."""
     flags = oracle.block_flags(st)
@@ -62,7 +72,7 @@ def test_oracle_block_flags_match_bruteforce_numpy():
     (20000, 400, 304, 250.0, {}),                      # ragged image edge (400 = 25 tiles, 304 = 19 tiles)
     (1500, 200, 120, 120.0, dict(scale_lo=0.05, scale_hi=0.4)),   # large splats: long lists, saturating pixels
 ])
-def test_hip_block_lists_equal_the_oracle_sets(P, W, H, focal, kw):
+def test_hip_block_lists_equal_the_oracle_sets(block_lists_on, P, W, H, focal, kw):
     import torch
 
     from based_on_point_cloud_partitions_amd import rasterizer as rz
@@ -102,3 +112,42 @@ def test_hip_block_lists_equal_the_oracle_sets(P, W, H, focal, kw):
             want_mask[offs[i] + (ty - mny) * (mxx - mnx) + (tx - mnx), q] = 1
     assert total > 0
     assert np.array_equal(bmask, want_mask)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,W,H,focal,kw", [
+    (6000, 256, 192, 150.0, dict(scale_lo=0.01, scale_hi=0.08)),
+    (20000, 400, 304, 250.0, {}),
+    (1500, 200, 120, 120.0, dict(scale_lo=0.05, scale_hi=0.4)),
+    (64, 13, 143, 40.0, dict(scale_lo=0.02, scale_hi=1.0)),          # one tile column, ragged
+    (60000, 2100, 2100, 1500.0, dict(scale_lo=0.004, scale_hi=0.03)),  # 17,424 tiles, mostly short lists
+])
+def test_gaussian_per_lane_backward_matches_the_oracle(block_lists_on, P, W, H, focal, kw):
+    """render_backward_skew.hip (GSR_BLK=1) against the oracle's gradients, same bar as the default kernel."""
+    from helpers import assert_forward_bit_exact, assert_grads_close, hip_backward_raw
+
+    g, cam = scene(P, W, H, focal, seed=11, **kw)
+    bg = (0.3, 0.0, 0.6)
+    st = oracle_forward(g, cam, bg=bg)
+    ctx = hip_forward_raw(g, cam, bg=bg)
+    assert_forward_bit_exact(ctx, st)  # the list-building forward renders the same image, bit for bit
+    dL = np.random.default_rng(2).standard_normal((3, H, W)).astype(np.float32)
+    assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+
+
+@pytest.mark.gpu
+def test_gaussian_per_lane_backward_config2_size(block_lists_on):
+    """Full 500k-Gaussian 1080p frame: every gradient row is written exactly once (the result matches the default kernel's)."""
+    import torch
+
+    from based_on_point_cloud_partitions_amd import _lib
+    from helpers import assert_grads_close, hip_backward_raw
+
+    g, cam = scene(500_000, 1920, 1080, 1200.0, seed=0, n_cams=16)
+    dL = np.random.default_rng(3).standard_normal((3, 1080, 1920)).astype(np.float32)
+    got = hip_backward_raw(hip_forward_raw(g, cam), dL)
+    _lib.set_variant("BLK", 0)
+    want = hip_backward_raw(hip_forward_raw(g, cam), dL)
+    _lib.set_variant("BLK", 1)
+    assert_grads_close(got, want, tol=2e-5)
+    torch.cuda.empty_cache()
