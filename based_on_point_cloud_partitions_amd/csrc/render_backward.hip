@@ -169,9 +169,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
     __syncthreads();
     const uint32_t hi = __builtin_amdgcn_readfirstlane(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
 
-    float accum0 = 0.f, accum1 = 0.f, accum2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    float accum0 = 0.f, accum1 = 0.f, accum2 = 0.f;
     float* my_acc = s_acc + wave * ACC_STRIDE;
-    const float parked_x = 1e30f;
     const int rounds = (int)((hi + BATCH - 1) / BATCH);
     // reduce-scatter constants: lane masks and the accumulator slot this lane writes
     const unsigned long long M0 = 0xAAAAAAAAAAAAAAAAull, M1 = 0xCCCCCCCCCCCCCCCCull, M2 = 0xF0F0F0F0F0F0F0F0ull,
@@ -226,14 +225,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
             const float4 a = s_a[j];
             const float4 b = s_b[j];
             const uint32_t kidx = __float_as_uint(b.w);  // position of this entry in the tile's list
-            // entries behind this pixel's last contributor are parked far away (power -> -inf / NaN), so one range test
-            // covers `kidx < last_contributor`, `power <= 0` and the conservative alpha < 1/255 shortcut
+            // entries behind this pixel's last contributor never reach it (backward.cu:480-482): their lanes are masked out of
+            // every lane mask below (no per-lane select on the pixel position -- a select costs 4.4 cycles, a scalar AND nothing)
             const unsigned long long m_act = __builtin_amdgcn_ballot_w64(kidx < last_contributor);
-            float px;
-            // s_nop 1: the mask was just written by a VALU compare (2 wait states before a VALU reads it as an operand;
-            // the compiler pads its own selects the same way but does not look inside asm)
-            asm("s_nop 1\n v_cndmask_b32 %0, %1, %2, %3" : "=v"(px) : "v"(parked_x), "v"(pixf_x), "s"(m_act));
-            const float dx = a.x - px, dy = a.y - pixf_y;
+            const float dx = a.x - pixf_x, dy = a.y - pixf_y;
             // identical to the forward (CONTRACT-FMA)
             const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
             const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
@@ -241,9 +236,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
             // compare's result mask): combining them and testing "any lane" is scalar work, and the two selects below take
             // the mask directly.  Written with bools, the compiler re-materialises every combined predicate through
             // v_cndmask + v_cmp_ne (two half-rate VALU instructions per test).
-            const unsigned long long m_maybe = __builtin_amdgcn_ballot_w64(power >= b.z);  // power > 0 is tested below
+            const unsigned long long m_maybe = m_act & __builtin_amdgcn_ballot_w64(power >= b.z);  // power > 0 is tested below
             if (m_maybe == 0ull) continue;  // wave-uniform
-            unsigned long long m_c = m_maybe & m_act & __builtin_amdgcn_ballot_w64(power <= 0.0f);
+            unsigned long long m_c = m_maybe & __builtin_amdgcn_ballot_w64(power <= 0.0f);
             // G = exp(power) from the hardware exp2 (v_exp_f32, <= 1e-6 relative off gsr_expf on the range that can pass),
             // 2 issue slots instead of the 17 instructions of the forward's fully specified gsr_expf.  The alpha >= 1/255
             // decision must be the forward's: when any lane's alpha lies within 8e-6 (relative) of the threshold the wave
@@ -257,23 +252,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
             m_c &= __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
             if (m_c == 0ull) continue;  // wave-uniform
             // From here all 64 lanes run the same straight-line code.  A lane that does not contribute is given alpha = G = 0:
-            // then T/(1-0) = T, its gradient terms vanish, and the colour recurrence (backward.cu:515) folds the pending
-            // (last_alpha, last_color) into accum exactly once -- the same value the next real contributor would have
-            // computed -- so no per-variable select is needed.
+            // then T/(1-0) = T, its gradient terms vanish, and the colour recurrence (backward.cu:515) leaves accum unchanged
+            // (0 * c + 1 * accum) -- so no per-variable select is needed.
             float Ge, ae;
             asm("v_cndmask_b32 %0, 0, %2, %4\n v_cndmask_b32 %1, 0, %3, %4" : "=&v"(Ge), "=v"(ae) : "v"(G), "v"(alpha), "s"(m_c));
             const float4 c = s_c[j];
-            const float inv = __builtin_amdgcn_rcpf(1.f - ae);
+            const float oma = 1.f - ae;
+            const float inv = __builtin_amdgcn_rcpf(oma);
             T = T * inv;  // T / (1 - alpha), backward.cu:502
-            const float oma = 1.f - last_alpha;
-            accum0 = __builtin_fmaf(last_alpha, lc0, oma * accum0);
-            accum1 = __builtin_fmaf(last_alpha, lc1, oma * accum1);
-            accum2 = __builtin_fmaf(last_alpha, lc2, oma * accum2);
-            lc0 = c.x; lc1 = c.y; lc2 = c.z;
-            last_alpha = ae;
+            // accum0..2 hold the colour accumulated behind this entry (backward.cu:515 already applied for the previous one)
             float dL_dalpha = (c.x - accum0) * dL0;
             dL_dalpha = __builtin_fmaf(c.y - accum1, dL1, dL_dalpha);
             dL_dalpha = __builtin_fmaf(c.z - accum2, dL2, dL_dalpha);
+            // ... and the recurrence for the next one right away, same operands and order as the reference evaluates it there:
+            // accum = last_alpha * last_color + (1 - last_alpha) * accum (no last_alpha / last_color registers to carry)
+            accum0 = __builtin_fmaf(ae, c.x, oma * accum0);
+            accum1 = __builtin_fmaf(ae, c.y, oma * accum1);
+            accum2 = __builtin_fmaf(ae, c.z, oma * accum2);
             dL_dalpha *= T;
             dL_dalpha = __builtin_fmaf(-T_final * inv, bg_dot, dL_dalpha);
             const float w = Ge * dL_dalpha;
