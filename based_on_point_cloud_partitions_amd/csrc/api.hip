@@ -222,6 +222,7 @@ static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_byte
     char* g = (char*)geom_buffer;
     a.splat = (float*)(g + L.splat); a.cov3D = (float*)(g + L.cov3D); a.clamped = (uint8_t*)(g + L.clamped);
     a.tiles_touched = (uint32_t*)(g + L.tiles_touched); a.block_sums = (uint32_t*)(g + L.block_sums);
+    a.row_block_sums = (uint32_t*)(g + L.row_block_sums);
     { StageTimer t(GSR_STAGE_PREPROCESS, s); gsr_launch_preprocess(a, s); }
     const int nb = (P + 255) / 256;
     unsigned long long* mail_dev = nullptr;
@@ -229,8 +230,8 @@ static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_byte
     w->total_dev = g + L.total;
     {
         StageTimer t(GSR_STAGE_SCAN, s);
-        gsr_launch_scan_blocks(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), w->mail ? mail_dev : nullptr,
-                               w->seq, s);
+        gsr_launch_scan_blocks2(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), a.row_block_sums,
+                                (uint32_t*)(g + L.row_block_offsets), w->mail ? mail_dev : nullptr, w->seq, s);
     }
     return 0;
 }
@@ -306,7 +307,8 @@ static void launch_render_head(int P, int W, int H, void* geom_buffer, void* bin
     {   // per-Gaussian instance offsets only (needed by the backward's gradient-row addressing)
         StageTimer t(GSR_STAGE_EMIT, s);
         gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched), (const uint32_t*)(g + G.block_offsets),
-                        (uint32_t*)(g + G.point_offsets), nullptr, nullptr, (uint32_t*)(b + B.band), s);
+                        (uint32_t*)(g + G.point_offsets), (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets), nullptr,
+                        nullptr, (uint32_t*)(b + B.band), s);
     }
     StageTimer t(GSR_STAGE_SORT, s);
     gsr_launch_tile_binning_head(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
@@ -354,7 +356,8 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
         {
             StageTimer t(GSR_STAGE_EMIT, s);
             gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
-                            (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets), ka, va, nullptr, s);
+                            (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets),
+                            (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets), ka, va, nullptr, s);
         }
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));  // rasterizer_impl.cu:300-308
         int in_b;
@@ -370,6 +373,7 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
         // point_offsets must still be valid for the backward pass; no instances -> all ranges empty
         // (an early head, if any, wrote the same zeros)
         hipMemsetAsync(g + G.point_offsets, 0, (size_t)P * 4, s);
+        hipMemsetAsync(g + G.row_offsets, 0, (size_t)P * 4, s);
         gsr_launch_tile_ranges(0, nullptr, ranges, (uint32_t)(gx * gy), s);
     }
     {
@@ -496,6 +500,7 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);
     a.tiles_touched = (const uint32_t*)(g + G.tiles_touched);
     a.point_offsets = (const uint32_t*)(g + G.point_offsets);
+    a.row_offsets = (const uint32_t*)(g + G.row_offsets);
     a.grad_rows = (const float*)(sc + S.rows);
     a.rowinfo = (R > 0 && lists) ? (const uint32_t*)(sc + S.rowinfo) : nullptr;
     { StageTimer t(GSR_STAGE_GAUSS_BWD, s); gsr_launch_gaussian_backward(a, s); }

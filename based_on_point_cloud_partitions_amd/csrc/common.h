@@ -8,22 +8,29 @@
 #define GSR_TILE_X 16
 #define GSR_TILE_Y 16
 #define GSR_TILE_PIX 256
-#define GSR_SPLAT_F 12   // floats per packed per-Gaussian record (48 B)
+#define GSR_SPLAT_F 16   // floats per packed per-Gaussian record (64 B, 64-byte aligned: a gather never straddles a line)
 #define GSR_GROW_F 12    // floats per per-instance gradient row (48 B)
 
 // Packed per-Gaussian record written by the preprocess kernel and gathered by the blend kernels.
-// One 48-byte row (3 x 16 B loads) instead of the reference's four separate arrays
-// (means2D / conic_opacity / rgb / depths, rasterizer_impl.h:29-45).
+// One 64-byte row (16 B quarters) instead of the reference's four separate arrays
+// (means2D / conic_opacity / rgb / depths, rasterizer_impl.h:29-45).  The forward blend reads the first three quarters.
+// Fourth quarter = gradient-row bookkeeping of the backward: which tiles of the Gaussian's rectangle its alpha >= 1/255 ellipse
+// can reach at all (gsr_tile_cannot_touch; 2/3 of the instances of a typical frame cannot be reached), as a bit mask over the
+// rectangle in row-major order, and the number of the Gaussian's first gradient row.  Only reachable instances own a row.
+// Rectangles of more than 64 tiles set SP_BIG instead: every instance owns a row (numbered by its position in the rectangle).
 enum SplatField {
     SP_MX = 0, SP_MY = 1, SP_CX = 2, SP_CY = 3, SP_CZ = 4, SP_OPA = 5,
-    SP_R = 6, SP_G = 7, SP_B = 8, SP_DEPTH = 9, SP_RADIUS = 10 /* int bits */, SP_OFFS = 11 /* uint bits: exclusive instance offset */
+    SP_R = 6, SP_G = 7, SP_B = 8, SP_DEPTH = 9, SP_RADIUS = 10 /* int bits */, SP_OFFS = 11 /* uint bits: exclusive instance offset */,
+    SP_ROWBASE = 12 /* uint bits: first gradient row */, SP_MASK_LO = 13, SP_MASK_HI = 14 /* reachable tiles of the rectangle */,
+    SP_BIG = 15 /* uint bits: 1 = rectangle of more than 64 tiles, no mask */
 };
 
 // Per-instance gradient row written by the backward blend kernel, summed per Gaussian afterwards.
 enum GradRowField { GR_MX = 0, GR_MY = 1, GR_CX = 2, GR_CY = 3, GR_CW = 4, GR_OPA = 5, GR_R = 6, GR_G = 7, GR_B = 8 };
 
 struct GeomLayout {
-    size_t splat, cov3D, clamped, tiles_touched, point_offsets, block_sums, block_offsets, total, radii, bytes;
+    size_t splat, cov3D, clamped, tiles_touched, point_offsets, block_sums, block_offsets, total, radii,
+        row_offsets /* inclusive prefix of the Gaussians' gradient-row counts */, row_block_sums, row_block_offsets, bytes;
 };
 struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
@@ -53,6 +60,9 @@ static inline GeomLayout gsr_geom_layout(int P)
     L.block_offsets = o; o = gsr_align(o + nb * 4);
     L.total = o; o = gsr_align(o + 16);
     L.radii = o; o = gsr_align(o + p * 4);
+    L.row_offsets = o; o = gsr_align(o + p * 4);
+    L.row_block_sums = o; o = gsr_align(o + nb * 4);
+    L.row_block_offsets = o; o = gsr_align(o + nb * 4 + 16);  // + the total
     L.bytes = o;
     return L;
 }
@@ -135,7 +145,7 @@ struct PreprocessArgs {
     const float *viewmatrix, *projmatrix, *campos;
     float scale_modifier, tan_fovx, tan_fovy;
     int* radii;
-    float* splat; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched; uint32_t* block_sums;
+    float* splat; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched; uint32_t* block_sums; uint32_t* row_block_sums;
     // raw-parameter mode (gsr_forward_params): scales / rotations / opacities hold the PRE-activation parameters of
     // scene/gaussian_model.py:102-122 and the SH rows come from the two tensors features_dc [P][1][3] / features_rest [P][M-1][3]
     int raw;
@@ -144,8 +154,12 @@ struct PreprocessArgs {
 void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
                             unsigned long long* mailbox, uint32_t seq, hipStream_t s);
+// the same with a second, independent array scanned in the same launch (in2 may be NULL); total2 = out2 + nblocks
+void gsr_launch_scan_blocks2(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, const uint32_t* in2,
+                             uint32_t* out2, unsigned long long* mailbox, uint32_t seq, hipStream_t s);
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                     uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, uint32_t* band_mem, hipStream_t s);
+                     uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint64_t* keys, uint32_t* vals,
+                     uint32_t* band_mem, hipStream_t s);
 #define GSR_BAND_COUNTERS 64  // band_mem = [64 counters][nb * P ids]
 // true (and the band count / height in tile rows) when the banded tile binning applies to this tile grid
 bool gsr_band_geometry(int gx, int gy, int* nb, int* bh);
@@ -181,6 +195,7 @@ struct GaussBackwardArgs {
     int P, D, M, W, H;
     const float *means3D, *shs, *scales, *rotations, *cov3D_in /* precomp or computed */, *viewmatrix, *projmatrix, *campos;
     const int* radii; const uint8_t* clamped; const float* splat; const uint32_t* tiles_touched; const uint32_t* point_offsets;
+    const uint32_t* row_offsets;
     float scale_modifier, tan_fovx, tan_fovy;
     int has_shs, has_scales;
     const float* grad_rows;
@@ -391,6 +406,57 @@ __device__ __forceinline__ bool gsr_tile_cannot_touch(float mx, float my, float 
         }
     }
     return qmin > t + (1e-3f * fabsf(t) + 1e-5f * qabs + 1e-3f);  // NaN anywhere -> false (keep)
+}
+
+// Gradient rows a Gaussian owns: the reachable tiles of its rectangle, or all of them for a rectangle too large for the mask
+__device__ __forceinline__ uint32_t gsr_splat_rows(uint32_t mask_lo, uint32_t mask_hi, uint32_t big, uint32_t tiles_touched)
+{
+    return big ? tiles_touched : (uint32_t)(__popc(mask_lo) + __popc(mask_hi));
+}
+
+// Which tiles of a splat's rectangle [mnx, mxx) x [mny, mxy) (at most 64 tiles) can its alpha >= 1/255 ellipse reach?  Bit
+// (ty - mny) * (mxx - mnx) + (tx - mnx) is set if any pixel centre of tile (tx, ty) may satisfy
+// q = cx u^2 + 2 cy u v + cz v^2 <= t, t = 2 ln(255 opacity), (u, v) = pixel - mean.  CONSERVATIVE (margins far above the fp32
+// rounding of the blend kernels' own evaluation): a cleared bit guarantees that no pixel of the tile blends the splat, so the
+// instance needs no gradient row.  Per tile ROW the reachable tiles are an interval -- the ellipse cut by the row's band of pixel
+// centres is convex -- whose ends are the band's extreme chord points: u(v) = -(cy/cx) v +- sqrt(cx t - det v^2) / cx is concave /
+// convex in v, so each end is one evaluation at the clamped unconstrained optimum.  ~40 instructions per tile row instead of a
+// ~100-instruction test per tile.
+__device__ __forceinline__ unsigned long long gsr_reach_mask(float mx, float my, float cx, float cy, float cz, float opacity,
+                                                             uint32_t mnx, uint32_t mny, uint32_t mxx, uint32_t mxy)
+{
+    const uint32_t w = mxx - mnx, h = mxy - mny, n = w * h;
+    const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    if (!(opacity > 0.f)) return all;                       // opacity <= 0 or NaN: everything is left to the exact path
+    float t = 2.0f * __logf(255.0f * opacity);
+    t = t + (2e-3f * fabsf(t) + 5e-3f);                     // margin of the blend kernels' own skip threshold and then some
+    if (t < 0.f) return 0ull;                               // alpha < 1/255 even at the centre
+    const float det = cx * cz - cy * cy;
+    if (!(cx > 0.f) || !(cz > 0.f) || !(det > 0.f) || !(det < INFINITY)) return all;  // not an ellipse: no statement
+    const float inv_cx = 1.0f / cx, inv_det = 1.0f / det;
+    const float vmax = sqrtf(cx * t * inv_det) * 1.001f + 0.02f;   // |v| extent of the ellipse
+    const float umax_g = sqrtf(cz * t * inv_det);                  // |u| extent; it is reached at v = -+(cy / cz) * umax_g
+    const float vstar = -(cy / cz) * umax_g;                       // v of the right-most point (left-most: -vstar)
+    const float slope = -cy * inv_cx;
+    unsigned long long mask = 0ull;
+    for (uint32_t ty = mny; ty < mxy; ty++) {
+        const float vl = (float)(ty * GSR_TILE_Y) - my, vh = vl + (float)(GSR_TILE_Y - 1);
+        if (vl > vmax || vh < -vmax) continue;                     // the band misses the ellipse
+        // right end: maximise the concave u_max(v) over the band; left end: minimise the convex u_min(v)
+        const float vr = fminf(fmaxf(vstar, vl), vh), vq = fminf(fmaxf(-vstar, vl), vh);
+        const float dr = fmaxf(cx * t - det * vr * vr, 0.f), dq = fmaxf(cx * t - det * vq * vq, 0.f);
+        const float ur = slope * vr + sqrtf(dr) * inv_cx, ul = slope * vq - sqrtf(dq) * inv_cx;
+        const float m = 0.02f + 1e-3f * (fabsf(ur) + fabsf(ul));
+        // tiles whose pixel centres [16 tx, 16 tx + 15] meet [mx + ul - m, mx + ur + m]
+        const float lo_f = ceilf((mx + ul - m - (float)(GSR_TILE_X - 1)) * (1.0f / GSR_TILE_X));
+        const float hi_f = floorf((mx + ur + m) * (1.0f / GSR_TILE_X));
+        const int lo = max((int)mnx, (int)fmaxf(lo_f, -1.0f)), hi = min((int)mxx - 1, (int)fminf(hi_f, 1.0e6f));
+        if (lo > hi) continue;
+        const uint32_t cnt = (uint32_t)(hi - lo + 1);
+        const unsigned long long run = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        mask |= run << ((ty - mny) * w + ((uint32_t)lo - mnx));
+    }
+    return mask & all;
 }
 
 // auxiliary.h:46-56 -- tile rectangle of a splat (saturating float->int as the hardware converts)

@@ -28,7 +28,7 @@ struct GaussBackwardPtrs {
     const float* __restrict__ rotations; const float* __restrict__ cov3D_in; const float* __restrict__ viewmatrix;
     const float* __restrict__ projmatrix; const float* __restrict__ campos; const int* __restrict__ radii;
     const uint8_t* __restrict__ clamped; const float* __restrict__ splat; const uint32_t* __restrict__ tiles_touched;
-    const float* __restrict__ grad_rows; const uint32_t* __restrict__ point_offsets;
+    const float* __restrict__ grad_rows; const uint32_t* __restrict__ point_offsets; const uint32_t* __restrict__ row_offsets;
     // non-NULL: rows are numbered by rowinfo (render_backward_skew.hip: one row per marked (instance slot, quadrant) pair, raw
     // moments); NULL: one finished row per instance slot (render_backward.hip)
     const uint32_t* __restrict__ rowinfo;
@@ -64,19 +64,27 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {
         const int first = blockIdx.x * BS, last = min(a.P, first + BS);
-        uint32_t begin = first == 0 ? 0u : a.point_offsets[first - 1];
-        uint32_t end = a.point_offsets[last - 1];
-        uint32_t my_off = 0, my_n = 0;
-        if (visible) {
-            my_off = __float_as_uint(a.splat[(size_t)idx * GSR_SPLAT_F + SP_OFFS]);
-            my_n = a.tiles_touched[idx];
-        }
-        if (a.rowinfo) {  // instance slots -> row numbers (the rows of consecutive slots are consecutive)
+        uint32_t begin, end, my_off = 0, my_n = 0;
+        if (a.rowinfo) {  // rows numbered by rowinfo over the instance slots (render_backward_skew.hip)
+            begin = first == 0 ? 0u : a.point_offsets[first - 1];
+            end = a.point_offsets[last - 1];
+            if (visible) {
+                my_off = __float_as_uint(a.splat[(size_t)idx * GSR_SPLAT_F + SP_OFFS]);
+                my_n = a.tiles_touched[idx];
+            }
             begin = a.rowinfo[begin] >> 4;
             end = a.rowinfo[end] >> 4;
             if (visible) {
                 const uint32_t r0 = a.rowinfo[my_off] >> 4, r1 = a.rowinfo[my_off + my_n] >> 4;
                 my_off = r0; my_n = r1 - r0;
+            }
+        } else {      // one row per reachable instance, numbered by the preprocess kernel's tile masks (render_backward.hip)
+            begin = first == 0 ? 0u : a.row_offsets[first - 1];
+            end = a.row_offsets[last - 1];
+            if (visible) {
+                const float4 q3 = *reinterpret_cast<const float4*>(a.splat + (size_t)idx * GSR_SPLAT_F + 12);
+                my_off = __float_as_uint(q3.x);
+                my_n = gsr_splat_rows(__float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w), a.tiles_touched[idx]);
             }
         }
         const uint32_t CH = (uint32_t)a.lds_floats / GSR_GROW_F;  // rows per chunk
@@ -382,7 +390,7 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.means3D = a.means3D; p.shs = a.shs; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_in = a.cov3D_in;
     p.viewmatrix = a.viewmatrix; p.projmatrix = a.projmatrix; p.campos = a.campos; p.radii = a.radii; p.clamped = a.clamped;
     p.splat = a.splat; p.tiles_touched = a.tiles_touched; p.grad_rows = a.grad_rows; p.point_offsets = a.point_offsets;
-    p.rowinfo = a.rowinfo; p.half_w = 0.5f * a.W; p.half_h = 0.5f * a.H;
+    p.row_offsets = a.row_offsets; p.rowinfo = a.rowinfo; p.half_w = 0.5f * a.W; p.half_h = 0.5f * a.H;
     p.dL_dmeans2D = a.dL_dmeans2D; p.dL_dcolors = a.dL_dcolors; p.dL_dopacity = a.dL_dopacity; p.dL_dmeans3D = a.dL_dmeans3D;
     p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscales = a.dL_dscales; p.dL_drots = a.dL_drots;
     p.features_dc = a.features_dc; p.features_rest = a.features_rest;

@@ -64,7 +64,7 @@ struct PreprocessPtrs {
     const float* __restrict__ campos; const float* __restrict__ features_dc; const float* __restrict__ features_rest;
     float scale_modifier, tan_fovx, tan_fovy;
     int* __restrict__ radii; float* __restrict__ splat; float* __restrict__ cov3D; uint8_t* __restrict__ clamped;
-    uint32_t* __restrict__ tiles_touched; uint32_t* __restrict__ block_sums;
+    uint32_t* __restrict__ tiles_touched; uint32_t* __restrict__ block_sums; uint32_t* __restrict__ row_block_sums;
 };
 
 // RAW: scales / rotations / opacities are the pre-activation parameters (exp / normalize / sigmoid applied here) and the
@@ -87,9 +87,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
         sh_tile_load(a.shs + (size_t)blockIdx.x * 256 * n3, s_sh, min(256, a.P - (int)blockIdx.x * 256), n3, sh_stride);
         __syncthreads();
     }
-    uint32_t touched = 0;
+    uint32_t touched = 0, rows = 0;
     if (idx < a.P) {
-        float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;  // culled: radius 0
+        float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0, rec3 = rec0;  // culled: radius 0
         int radius_out = 0;
         const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
         const float* pm = a.projmatrix;
@@ -190,56 +190,75 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
                     rec2 = make_float4(cb, tz, __int_as_float(iradius), 0.0f);
                     radius_out = iradius;
                     touched = area;
+                    // which tiles of the rectangle can the alpha >= 1/255 ellipse reach at all?  Decides which instances own a
+                    // gradient row (common.h, gsr_reach_mask); the backward blend drops the others from its walk
+                    if (area <= 64) {
+                        const unsigned long long mask = gsr_reach_mask(pix_x, pix_y, conx, cony, conz, opa, mnx, mny, mxx, mxy);
+                        rec3 = make_float4(0.f, __uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)), __uint_as_float(0u));
+                        rows = (uint32_t)__popcll(mask);
+                    } else {
+                        rec3 = make_float4(0.f, 0.f, 0.f, __uint_as_float(1u));
+                        rows = area;
+                    }
                 }
             }
         }
         float4* rec = reinterpret_cast<float4*>(a.splat + (size_t)idx * GSR_SPLAT_F);
-        rec[0] = rec0; rec[1] = rec1; rec[2] = rec2;
+        rec[0] = rec0; rec[1] = rec1; rec[2] = rec2; rec[3] = rec3;
         a.radii[idx] = radius_out;
         a.tiles_touched[idx] = touched;
     }
-    // workgroup sum of tiles_touched
-    uint32_t v = touched;
+    // workgroup sums of tiles_touched and of the gradient-row counts
+    uint32_t v = touched, r = rows;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-    __shared__ uint32_t wsum[4];
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    for (int off = 32; off >= 1; off >>= 1) { v += __shfl_down(v, off, 64); r += __shfl_down(r, off, 64); }
+    __shared__ uint32_t wsum[4], rsum[4];
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = v; rsum[threadIdx.x >> 6] = r; }
     __syncthreads();
-    if (threadIdx.x == 0) a.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        a.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        a.row_block_sums[blockIdx.x] = rsum[0] + rsum[1] + rsum[2] + rsum[3];
+    }
 }
 
 // Exclusive scan of the per-workgroup sums (single workgroup, 1024 threads, chunked with a carry).
 // `mailbox` (optional) is a word of host-mapped pinned memory: the total is published there, tagged with `seq`, so the
 // host can pick it up by polling instead of queueing a copy and synchronising the stream.
 __global__ void __launch_bounds__(1024) scan_blocks_kernel(int n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                            uint32_t* __restrict__ total, unsigned long long* mailbox, uint32_t seq)
+                                                            uint32_t* __restrict__ total, const uint32_t* __restrict__ in2,
+                                                            uint32_t* __restrict__ out2, unsigned long long* mailbox, uint32_t seq)
 {
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    __shared__ uint32_t wtot[16], wtot2[16];
+    __shared__ uint32_t carry_s, carry2_s;
+    if (threadIdx.x == 0) { carry_s = 0; carry2_s = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
         const uint32_t v = i < n ? in[i] : 0u;
-        uint32_t incl = v;
+        const uint32_t v2 = (in2 && i < n) ? in2[i] : 0u;
+        uint32_t incl = v, incl2 = v2;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
+            const uint32_t t = __shfl_up(incl, off, 64), t2 = __shfl_up(incl2, off, 64);
+            if (lane >= off) { incl += t; incl2 += t2; }
         }
-        if (lane == 63) wtot[wave] = incl;
+        if (lane == 63) { wtot[wave] = incl; wtot2[wave] = incl2; }
         __syncthreads();
-        uint32_t wbase = 0;
-        for (int w = 0; w < wave; w++) wbase += wtot[w];
-        const uint32_t carry = carry_s;
-        if (i < n) out[i] = carry + wbase + incl - v;
+        uint32_t wbase = 0, wbase2 = 0;
+        for (int w = 0; w < wave; w++) { wbase += wtot[w]; wbase2 += wtot2[w]; }
+        const uint32_t carry = carry_s, carry2 = carry2_s;
+        if (i < n) {
+            out[i] = carry + wbase + incl - v;
+            if (in2) out2[i] = carry2 + wbase2 + incl2 - v2;
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
+        if (threadIdx.x == 1023) { carry_s = carry + wbase + incl; carry2_s = carry2 + wbase2 + incl2; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         *total = carry_s;
+        if (in2) out2[n] = carry2_s;
         if (mailbox)
             __hip_atomic_store(mailbox, ((unsigned long long)seq << 32) | carry_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -254,30 +273,40 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(int n, const uint32_t
 __global__ void __launch_bounds__(256) emit_keys_kernel(int P, int gx, int gy, float* __restrict__ splat,
                                                         const uint32_t* __restrict__ tiles_touched,
                                                         const uint32_t* __restrict__ block_offsets,
-                                                        uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals, uint32_t* __restrict__ band_count)
+                                                        uint32_t* __restrict__ point_offsets,
+                                                        const uint32_t* __restrict__ row_block_offsets, uint32_t* __restrict__ row_offsets,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        uint32_t* __restrict__ band_count)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (band_count && blockIdx.x == 0 && threadIdx.x < GSR_BAND_COUNTERS) band_count[threadIdx.x] = 0;
     const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
-    uint32_t incl = n;
+    // gradient rows of this Gaussian (fourth quarter of its record, written by the preprocess kernel)
+    uint32_t nr = 0;
+    if (n != 0) {
+        const float4 q3 = *reinterpret_cast<const float4*>(splat + (size_t)idx * GSR_SPLAT_F + 12);
+        nr = gsr_splat_rows(__float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w), n);
+    }
+    uint32_t incl = n, incl_r = nr;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
+        const uint32_t t = __shfl_up(incl, off, 64), tr = __shfl_up(incl_r, off, 64);
+        if (lane >= off) { incl += t; incl_r += tr; }
     }
-    __shared__ uint32_t wtot[4];
-    if (lane == 63) wtot[wave] = incl;
+    __shared__ uint32_t wtot[4], wtot_r[4];
+    if (lane == 63) { wtot[wave] = incl; wtot_r[wave] = incl_r; }
     __syncthreads();
-    uint32_t base = block_offsets[blockIdx.x];
-    for (int w = 0; w < wave; w++) base += wtot[w];
+    uint32_t base = block_offsets[blockIdx.x], base_r = row_block_offsets[blockIdx.x];
+    for (int w = 0; w < wave; w++) { base += wtot[w]; base_r += wtot_r[w]; }
     if (idx >= P) return;
     const uint32_t end = base + incl;
     uint32_t off = end - n;
     point_offsets[idx] = end;
+    row_offsets[idx] = base_r + incl_r;
     if (n == 0) return;
     float* rec = splat + (size_t)idx * GSR_SPLAT_F;
+    rec[SP_ROWBASE] = __uint_as_float(base_r + incl_r - nr);
     const float mx = rec[SP_MX], my = rec[SP_MY];
     const uint32_t dbits = __float_as_uint(rec[SP_DEPTH]);
     const int radius = __float_as_int(rec[SP_RADIUS]);
@@ -331,7 +360,7 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     p.projmatrix = a.projmatrix; p.campos = a.campos;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     p.radii = a.radii; p.splat = a.splat; p.cov3D = a.cov3D; p.clamped = a.clamped; p.tiles_touched = a.tiles_touched;
-    p.block_sums = a.block_sums; p.features_dc = a.features_dc; p.features_rest = a.features_rest;
+    p.block_sums = a.block_sums; p.row_block_sums = a.row_block_sums; p.features_dc = a.features_dc; p.features_rest = a.features_rest;
     const size_t lds = (a.shs || a.raw) ? (size_t)256 * (3 * a.M + 1) * 4 : 0;
     if (a.raw)
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, focal_x, focal_y, gx, gy);
@@ -342,17 +371,24 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
                             unsigned long long* mailbox, uint32_t seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total, mailbox, seq);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total, nullptr, nullptr, mailbox, seq);
+}
+
+void gsr_launch_scan_blocks2(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, const uint32_t* in2,
+                             uint32_t* out2, unsigned long long* mailbox, uint32_t seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total, in2, out2, mailbox, seq);
 }
 
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                     uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, uint32_t* band_mem, hipStream_t s)
+                     uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint64_t* keys, uint32_t* vals,
+                     uint32_t* band_mem, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     int nb = 0, bh = 1;
     uint32_t* band_count = (band_mem && gsr_band_geometry(gx, gy, &nb, &bh)) ? band_mem : nullptr;
     hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, splat, tiles_touched, block_offsets,
-                       point_offsets, keys, vals, band_count);
+                       point_offsets, row_block_offsets, row_offsets, keys, vals, band_count);
 }
 
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s)

@@ -190,15 +190,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
             const uint32_t id = point_list[r0 + k];
             const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+            const float4 q3 = rec[3];  // gradient-row bookkeeping: first row, reachable tiles of the rectangle (common.h)
             uint32_t mnx, mny, mxx, mxy;
             gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
-            row = __float_as_uint(q2.w) + (by - mny) * (mxx - mnx) + (bx - mnx);
+            const uint32_t tilepos = (by - mny) * (mxx - mnx) + (bx - mnx);
             pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
-            keep = !gsr_tile_cannot_touch(q0.x, q0.y, q0.z, q0.w, q1.x, pthr, tile_x0, tile_y0);
-            if (!keep) {
-                float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                o[0] = z; o[1] = z; o[2] = z;
+            if (__float_as_uint(q3.w) == 0u) {
+                // the preprocess kernel has applied gsr_tile_cannot_touch to every tile of the rectangle: an unreachable instance
+                // owns no row and is dropped here; a reachable one is numbered by its rank among the reachable tiles
+                const unsigned long long mask = ((unsigned long long)__float_as_uint(q3.z) << 32) | __float_as_uint(q3.y);
+                keep = (mask >> tilepos) & 1ull;
+                row = __float_as_uint(q3.x) + (uint32_t)__popcll(mask & ((1ull << tilepos) - 1ull));
+            } else {  // rectangle of more than 64 tiles: every instance owns a row; unreachable ones get their zero row right here
+                row = __float_as_uint(q3.x) + tilepos;
+                keep = !gsr_tile_cannot_touch(q0.x, q0.y, q0.z, q0.w, q1.x, pthr, tile_x0, tile_y0);
+                if (!keep) {
+                    float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    o[0] = z; o[1] = z; o[2] = z;
+                }
             }
         }
         const unsigned long long bal = __ballot(keep);
@@ -309,14 +319,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
             o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
         }
     }
-    // list entries behind every pixel's last contributor: zero rows
+    // list entries behind every pixel's last contributor: zero rows (for those that own a row)
     for (uint32_t e = hi + tid; e < total; e += 256) {
         const uint32_t id = point_list[r0 + e];
         const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
-        const float4 q0 = rec[0], q2 = rec[2];
+        const float4 q0 = rec[0], q2 = rec[2], q3 = rec[3];
         uint32_t mnx, mny, mxx, mxy;
         gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
-        const uint32_t row = __float_as_uint(q2.w) + (by - mny) * (mxx - mnx) + (bx - mnx);
+        const uint32_t tilepos = (by - mny) * (mxx - mnx) + (bx - mnx);
+        uint32_t row;
+        if (__float_as_uint(q3.w) == 0u) {
+            const unsigned long long mask = ((unsigned long long)__float_as_uint(q3.z) << 32) | __float_as_uint(q3.y);
+            if (!((mask >> tilepos) & 1ull)) continue;
+            row = __float_as_uint(q3.x) + (uint32_t)__popcll(mask & ((1ull << tilepos) - 1ull));
+        } else
+            row = __float_as_uint(q3.x) + tilepos;
         float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         o[0] = z; o[1] = z; o[2] = z;
