@@ -433,19 +433,22 @@ __device__ __forceinline__ unsigned long long gsr_reach_mask(float mx, float my,
     if (t < 0.f) return 0ull;                               // alpha < 1/255 even at the centre
     const float det = cx * cz - cy * cy;
     if (!(cx > 0.f) || !(cz > 0.f) || !(det > 0.f) || !(det < INFINITY)) return all;  // not an ellipse: no statement
-    const float inv_cx = 1.0f / cx, inv_det = 1.0f / det;
-    const float vmax = sqrtf(cx * t * inv_det) * 1.001f + 0.02f;   // |v| extent of the ellipse
-    const float umax_g = sqrtf(cz * t * inv_det);                  // |u| extent; it is reached at v = -+(cy / cz) * umax_g
-    const float vstar = -(cy / cz) * umax_g;                       // v of the right-most point (left-most: -vstar)
+    // hardware reciprocal / square root (1 ulp): their error is orders of magnitude below the margins
+    const float inv_cx = __builtin_amdgcn_rcpf(cx), inv_det = __builtin_amdgcn_rcpf(det);
+    const float vmax = __builtin_amdgcn_sqrtf(cx * t * inv_det) * 1.001f + 0.02f;   // |v| extent of the ellipse
+    const float umax_g = __builtin_amdgcn_sqrtf(cz * t * inv_det);                  // |u| extent; it is reached at v = -+(cy / cz) * umax_g
+    const float vstar = -(cy * __builtin_amdgcn_rcpf(cz)) * umax_g;                 // v of the right-most point (left-most: -vstar)
     const float slope = -cy * inv_cx;
     unsigned long long mask = 0ull;
-    for (uint32_t ty = mny; ty < mxy; ty++) {
+    // tile rows whose band of pixel centres [16 ty, 16 ty + 15] meets [my - vmax, my + vmax]
+    const int ty0 = max((int)mny, (int)fmaxf(ceilf((my - vmax - (float)(GSR_TILE_Y - 1)) * (1.0f / GSR_TILE_Y)), -1.0f));
+    const int ty1 = min((int)mxy - 1, (int)fminf(floorf((my + vmax) * (1.0f / GSR_TILE_Y)), 1.0e6f));
+    for (int ty = ty0; ty <= ty1; ty++) {
         const float vl = (float)(ty * GSR_TILE_Y) - my, vh = vl + (float)(GSR_TILE_Y - 1);
-        if (vl > vmax || vh < -vmax) continue;                     // the band misses the ellipse
         // right end: maximise the concave u_max(v) over the band; left end: minimise the convex u_min(v)
         const float vr = fminf(fmaxf(vstar, vl), vh), vq = fminf(fmaxf(-vstar, vl), vh);
         const float dr = fmaxf(cx * t - det * vr * vr, 0.f), dq = fmaxf(cx * t - det * vq * vq, 0.f);
-        const float ur = slope * vr + sqrtf(dr) * inv_cx, ul = slope * vq - sqrtf(dq) * inv_cx;
+        const float ur = slope * vr + __builtin_amdgcn_sqrtf(dr) * inv_cx, ul = slope * vq - __builtin_amdgcn_sqrtf(dq) * inv_cx;
         const float m = 0.02f + 1e-3f * (fabsf(ur) + fabsf(ul));
         // tiles whose pixel centres [16 tx, 16 tx + 15] meet [mx + ul - m, mx + ur + m]
         const float lo_f = ceilf((mx + ul - m - (float)(GSR_TILE_X - 1)) * (1.0f / GSR_TILE_X));
@@ -454,7 +457,7 @@ __device__ __forceinline__ unsigned long long gsr_reach_mask(float mx, float my,
         if (lo > hi) continue;
         const uint32_t cnt = (uint32_t)(hi - lo + 1);
         const unsigned long long run = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
-        mask |= run << ((ty - mny) * w + ((uint32_t)lo - mnx));
+        mask |= run << (((uint32_t)ty - mny) * w + ((uint32_t)lo - mnx));
     }
     return mask & all;
 }
