@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 
@@ -73,6 +73,7 @@ PROTOTYPES = {
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),
     "gsr_debug_export_blocks": (c_int, [c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_set_variant": (None, [ctypes.c_char_p, c_int]),
+    "gsr_get_variant": (c_int, [ctypes.c_char_p, c_int]),
     "gsr_profile_enable": (None, [c_int]),
     "gsr_profile_select": (None, [ctypes.c_uint32]),
     "gsr_profile_collect": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64), c_int]),
@@ -137,6 +138,11 @@ def profile_collect():
 def set_variant(name, value):
     """Overrides the experiment switch GSR_<name> for this process (tests / A-B runs)."""
     load().gsr_set_variant(name.encode(), int(value))
+
+
+def get_variant(name, default):
+    """Current value of the experiment switch GSR_<name> (`default` if it was never set)."""
+    return int(load().gsr_get_variant(name.encode(), int(default)))
 
 
 def check(status, what):

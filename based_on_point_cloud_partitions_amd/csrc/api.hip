@@ -171,9 +171,17 @@ static void gsr_variant_store(const char* name, int value)
 // faster than the pixel-per-lane kernel (profiles/README.md, round 2); kept as a tested alternative (GSR_BLK=1).
 bool gsr_block_lists_enabled() { return gsr_variant("BLK", 0) && gsr_variant("BIN", 1) && gsr_variant("WAVE8X8", 1); }
 
+// Tile lists without the (Gaussian, tile) instances the splat cannot reach (GSR_CULL, default on; needs the tile binning).  The
+// reference lists every tile of the square around the 3-sigma circle of the larger axis (auxiliary.h:46-56): on config 2, 58 % of
+// those instances lie outside the alpha >= 1/255 ellipse (gsr_reach_mask) and cannot contribute to any pixel.  Leaving them out
+// changes no pixel and no gradient; GSR_CULL=0 keeps the reference's lists bit for bit (sort keys, point_list, ranges, n_contrib).
+bool gsr_cull_enabled() { return gsr_variant("CULL", 1) && gsr_variant("BIN", 1); }
+
 extern "C" {
 
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+int gsr_get_variant(const char* name, int default_value) { return name ? gsr_variant(name, default_value) : default_value; }
 
 void gsr_set_variant(const char* name, int value)
 {

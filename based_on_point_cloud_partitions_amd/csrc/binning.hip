@@ -24,10 +24,17 @@ constexpr int TCHUNK = 16384;       // tiles histogrammed per pass (64 KB of LDS
 
 struct SliceRect {
     uint32_t mnx, mny, mxx, mxy, dbits;
+    unsigned long long mask;  // reachable tiles of the rectangle (bit = row-major position); ~0 = all (no culling, or > 64 tiles)
     bool visible;
+    // is tile (x, y) of the rectangle listed?  With `cull` the instances whose tile the splat's alpha >= 1/255 ellipse cannot
+    // reach (gsr_reach_mask, computed by the preprocess kernel) never enter a list: they could not contribute to any pixel.
+    __device__ __forceinline__ bool listed(uint32_t x, uint32_t y) const
+    {
+        return mask == ~0ull || ((mask >> ((y - mny) * (mxx - mnx) + (x - mnx))) & 1ull);
+    }
 };
 
-__device__ __forceinline__ SliceRect load_rect(const float* __restrict__ splat, int idx, int gx, int gy)
+__device__ __forceinline__ SliceRect load_rect(const float* __restrict__ splat, int idx, int gx, int gy, int cull)
 {
     SliceRect r;
     const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)idx * GSR_SPLAT_F);
@@ -36,6 +43,14 @@ __device__ __forceinline__ SliceRect load_rect(const float* __restrict__ splat, 
     r.visible = radius > 0;
     r.dbits = __float_as_uint(q2.y);
     gsr_get_rect(q0.x, q0.y, radius, gx, gy, r.mnx, r.mny, r.mxx, r.mxy);
+    r.mask = ~0ull;
+    if (cull && r.visible && (r.mxx - r.mnx) * (r.mxy - r.mny) < 64u) {  // (a full 64-tile mask is ~0 = "all" anyway)
+        const float4 q3 = rec[3];
+        if (__float_as_uint(q3.w) == 0u) {
+            r.mask = ((unsigned long long)__float_as_uint(q3.z) << 32) | __float_as_uint(q3.y);
+            // a mask of zero leaves `listed` false everywhere; keep ~0 reserved for "all"
+        }
+    }
     return r;
 }
 
@@ -43,7 +58,7 @@ __device__ __forceinline__ SliceRect load_rect(const float* __restrict__ splat, 
 // 1024 threads per workgroup: with ~500 slices there are only ~2 workgroups per CU, and each instance is a dependent
 // LDS-atomic -> global-store chain, so the latency is hidden by waves, not by work per thread.
 constexpr int SLICE_THREADS = 1024;
-__global__ void __launch_bounds__(SLICE_THREADS) tile_count_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
+__global__ void __launch_bounds__(SLICE_THREADS) tile_count_kernel(int P, int gpb, int gx, int gy, int T, int cull, const float* __restrict__ splat,
                                                          uint32_t* __restrict__ table)
 {
     extern __shared__ uint32_t s_hist[];
@@ -53,12 +68,12 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_count_kernel(int P, int gp
         for (int t = threadIdx.x; t < tn; t += SLICE_THREADS) s_hist[t] = 0;
         __syncthreads();
         for (int idx = first + threadIdx.x; idx < last; idx += SLICE_THREADS) {
-            const SliceRect r = load_rect(splat, idx, gx, gy);
+            const SliceRect r = load_rect(splat, idx, gx, gy, cull);
             if (!r.visible) continue;
             for (uint32_t y = r.mny; y < r.mxy; y++)
                 for (uint32_t x = r.mnx; x < r.mxx; x++) {
                     const int t = (int)(y * (uint32_t)gx + x) - tbase;
-                    if (t >= 0 && t < tn) atomicAdd(&s_hist[t], 1u);
+                    if (t >= 0 && t < tn && r.listed(x, y)) atomicAdd(&s_hist[t], 1u);
                 }
         }
         __syncthreads();
@@ -107,7 +122,7 @@ __global__ void __launch_bounds__(256) tile_colscan_kernel(int T, int nslices, u
 // classes, counting sort): the blend kernels take workgroup b -> tile order[b], so the long lists start first and the
 // short ones fill the tail of the launch (longest-processing-time-first).  Which tile a workgroup renders has no effect
 // on any result.
-__global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int gpb, int gx, int gy, int T, const float* __restrict__ splat,
+__global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int gpb, int gx, int gy, int T, int cull, const float* __restrict__ splat,
                                                            const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
                                                            uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
                                                            uint2* __restrict__ bins)
@@ -177,12 +192,12 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int 
         }
         __syncthreads();
         for (int idx = first + threadIdx.x; idx < last; idx += SLICE_THREADS) {
-            const SliceRect r = load_rect(splat, idx, gx, gy);
+            const SliceRect r = load_rect(splat, idx, gx, gy, cull);
             if (!r.visible) continue;
             for (uint32_t y = r.mny; y < r.mxy; y++)
                 for (uint32_t x = r.mnx; x < r.mxx; x++) {
                     const int t = (int)(y * (uint32_t)gx + x) - tbase;
-                    if (t >= 0 && t < tn) {
+                    if (t >= 0 && t < tn && r.listed(x, y)) {
                         const uint32_t slot = atomicAdd(&s_cur[t], 1u);
                         bins[slot] = make_uint2((uint32_t)idx, r.dbits);  // little-endian u64 = depth << 32 | id
                     }
@@ -203,7 +218,7 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int 
 constexpr int BAND_SLICES = 64;   // slices per band
 constexpr int NB_MAX = GSR_BAND_COUNTERS;  // bands
 
-struct BandGeom { int gx, gy, T, nb, bh, tmax; };  // bh = tile rows per band, tmax = bh * gx
+struct BandGeom { int gx, gy, T, nb, bh, tmax, cull; };  // bh = tile rows per band, tmax = bh * gx; cull: see SliceRect::listed
 
 __global__ void __launch_bounds__(SLICE_THREADS) band_partition_kernel(int P, BandGeom G, const float* __restrict__ splat,
                                                                         uint32_t* __restrict__ band_count, uint32_t* __restrict__ band_list)
@@ -214,7 +229,7 @@ __global__ void __launch_bounds__(SLICE_THREADS) band_partition_kernel(int P, Ba
     const int idx = blockIdx.x * SLICE_THREADS + threadIdx.x;
     int b0 = 0, b1 = -1;
     if (idx < P) {
-        const SliceRect r = load_rect(splat, idx, G.gx, G.gy);
+        const SliceRect r = load_rect(splat, idx, G.gx, G.gy, 0);
         if (r.visible && r.mxy > r.mny && r.mxx > r.mnx) { b0 = (int)r.mny / G.bh; b1 = (int)(r.mxy - 1) / G.bh; }
     }
     for (int b = b0; b <= b1; b++) atomicAdd(&cnt[b], 1u);
@@ -249,10 +264,11 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_count_banded_kernel(int P,
     uint32_t first, last;
     band_slice_range(band_count, b, sidx, first, last);
     for (uint32_t i = first + threadIdx.x; i < last; i += SLICE_THREADS) {
-        const SliceRect r = load_rect(splat, (int)band_list[(size_t)b * P + i], G.gx, G.gy);
+        const SliceRect r = load_rect(splat, (int)band_list[(size_t)b * P + i], G.gx, G.gy, G.cull);
         const uint32_t y0 = max(r.mny, row0), y1 = min(r.mxy, row1);
         for (uint32_t y = y0; y < y1; y++)
-            for (uint32_t x = r.mnx; x < r.mxx; x++) atomicAdd(&s_hist[(y - row0) * (uint32_t)G.gx + x], 1u);
+            for (uint32_t x = r.mnx; x < r.mxx; x++)
+                if (r.listed(x, y)) atomicAdd(&s_hist[(y - row0) * (uint32_t)G.gx + x], 1u);
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * G.tmax;
@@ -370,10 +386,11 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_banded_kernel(int 
     band_slice_range(band_count, b, sidx, first, last);
     for (uint32_t i = first + threadIdx.x; i < last; i += SLICE_THREADS) {
         const uint32_t idx = band_list[(size_t)b * P + i];
-        const SliceRect r = load_rect(splat, (int)idx, G.gx, G.gy);
+        const SliceRect r = load_rect(splat, (int)idx, G.gx, G.gy, G.cull);
         const uint32_t y0 = max(r.mny, row0), y1 = min(r.mxy, row1);
         for (uint32_t y = y0; y < y1; y++)
             for (uint32_t x = r.mnx; x < r.mxx; x++) {
+                if (!r.listed(x, y)) continue;
                 const uint32_t slot = atomicAdd(&s_cur[(y - row0) * (uint32_t)G.gx + x], 1u);
                 bins[slot] = make_uint2(idx, r.dbits);  // little-endian u64 = depth << 32 | id
             }
@@ -637,6 +654,7 @@ static BandGeom band_geom(int gx, int gy)
     G.bh = (gy + nb - 1) / nb;
     G.nb = (gy + G.bh - 1) / G.bh;
     G.tmax = G.bh * gx;
+    G.cull = gsr_cull_enabled() ? 1 : 0;
     return G;
 }
 
@@ -678,7 +696,7 @@ void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint3
         int gpb;
         const int ns = gsr_tile_slices(P, &gpb);
         const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
-        hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, G.cull, splat, table);
         hipLaunchKernelGGL(tile_colscan_kernel, dim3((T + 31) / 32), dim3(256), 0, s, T, ns, table, totals);
     }
 }
@@ -700,7 +718,7 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
         int gpb;
         const int ns = gsr_tile_slices(P, &gpb);
         const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
-        hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, splat, table, totals, ranges,
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, G.cull, splat, table, totals, ranges,
                            order, reinterpret_cast<uint2*>(bins));
     }
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<const unsigned long long*>(bins),

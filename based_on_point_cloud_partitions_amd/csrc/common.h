@@ -191,6 +191,7 @@ void gsr_launch_render_backward_skew(int W, int H, const uint32_t* order, const 
                                      const uint32_t* n_contrib, const float* dL_dpix, float* grad_rows, uint32_t* queue_heads, hipStream_t s);
 int gsr_variant(const char* name, int dflt);  // experiment switch read from the environment (GSR_<name>)
 bool gsr_block_lists_enabled();               // per-8x8-block lists in the forward + Gaussian-per-lane backward
+bool gsr_cull_enabled();                      // tile lists without the instances the splat's alpha >= 1/255 ellipse cannot reach
 struct GaussBackwardArgs {
     int P, D, M, W, H;
     const float *means3D, *shs, *scales, *rotations, *cov3D_in /* precomp or computed */, *viewmatrix, *projmatrix, *campos;

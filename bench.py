@@ -362,20 +362,31 @@ def main():
         return radii
 
     # untimed statistics pass: V and R per camera (every byte / flop figure is a function of them)
+    # The workload is described in the reference's terms (its tile lists: R instances, list lengths, n_contrib), so this pass
+    # builds the reference's lists (GSR_CULL=0); `listed` is what the product's default lists hold (instances the splat cannot
+    # reach are left out, api.hip gsr_cull_enabled).
     stats = []
     with torch.no_grad():
         from based_on_point_cloud_partitions_amd import rasterizer as rz
         e = torch.Tensor([])
+        cull = _lib.get_variant("CULL", 1)
         for c, r in zip(cams, rasterizers):
             s = r.raster_settings
-            R, _, radii, gb, bb, ib = rz.rasterize_gaussians_forward(s.bg, xyz, e, opac, scales, rots, 1.0, e, s.viewmatrix,
-                                                                     s.projmatrix, s.tanfovx, s.tanfovy, H, W, shs, 3, s.campos,
-                                                                     False, False)
-            ex = rz.debug_export(P, R, W, H, gb, bb, ib)
-            ln = (ex["ranges"][:, 1] - ex["ranges"][:, 0]).float()
-            stats.append(dict(V=int((radii > 0).sum()), R=int(R), tile_mean=float(ln.mean()), tile_max=int(ln.max()),
-                              n_contrib_mean=float(ex["n_contrib"].float().mean())))
-            del gb, bb, ib, ex
+            per = {}
+            for mode in (0, cull):
+                _lib.set_variant("CULL", mode)
+                R, _, radii, gb, bb, ib = rz.rasterize_gaussians_forward(s.bg, xyz, e, opac, scales, rots, 1.0, e, s.viewmatrix,
+                                                                         s.projmatrix, s.tanfovx, s.tanfovy, H, W, shs, 3, s.campos,
+                                                                         False, False)
+                ex = rz.debug_export(P, R, W, H, gb, bb, ib)
+                ln = (ex["ranges"][:, 1] - ex["ranges"][:, 0]).float()
+                if mode == 0:
+                    per = dict(V=int((radii > 0).sum()), R=int(R), tile_mean=float(ln.mean()), tile_max=int(ln.max()),
+                               n_contrib_mean=float(ex["n_contrib"].float().mean()))
+                per["listed"] = int(ln.sum())
+                del gb, bb, ib, ex
+            stats.append(per)
+        _lib.set_variant("CULL", cull)
     torch.cuda.empty_cache()
 
     # Per-stage HIP events cost a few microseconds of stream time per pair (16 pairs per step added ~9 % to the step), so:
@@ -506,8 +517,9 @@ def main():
                                "tile_list_mean": round(float(np.mean([u["tile_mean"] for u in used])), 1),
                                "tile_list_max": int(max(u["tile_max"] for u in used)),
                                "n_contrib_mean": round(float(np.mean([u["n_contrib_mean"] for u in used])), 1),
+                               "instances_listed_mean": round(float(np.mean([u["listed"] for u in used])), 1),
                                "per_camera": [{"V": u["V"], "R": u["R"], "tile_list_mean": round(u["tile_mean"], 1),
-                                               "tile_list_max": u["tile_max"]} for u in stats]},
+                                               "tile_list_max": u["tile_max"], "listed": u["listed"]} for u in stats]},
             "knn_init_ms": knn_ms,
             "rendered_mpix_per_s_fwd": round(world * N / 1e6 / (fwd_ms * 1e-3), 1) if fwd_ms > 0 else None,
             "roofline": roofline,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 12
+#define GSR_ABI_VERSION 13
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -224,6 +224,7 @@ int gsr_debug_export_blocks(int P, int64_t R, int W, int H, const void* binning_
 /* Overrides an experiment switch (environment GSR_<NAME>) for this process: A/B measurements and the tests
  * that keep the alternative kernels covered.  No switch changes a result beyond the documented tolerances. */
 void gsr_set_variant(const char* name, int value);
+int gsr_get_variant(const char* name, int default_value);
 
 /* Stand-alone stable LSD radix sort of (u64,u32) pairs on bits [0,end_bit) (the binning sort, exported for
  * tests).  Returns 0 if the result is in (keys_a, vals_a), 1 if in (keys_b, vals_b), negative on error.

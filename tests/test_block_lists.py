@@ -75,6 +75,19 @@ def test_oracle_block_flags_match_bruteforce_numpy():
 def test_hip_block_lists_equal_the_oracle_sets(block_lists_on, P, W, H, focal, kw):
     import torch
 
+    from based_on_point_cloud_partitions_amd import _lib
+    from based_on_point_cloud_partitions_amd import rasterizer as rz
+
+    _lib.set_variant("CULL", 0)  # the expected lists below are written in the reference's list positions
+    try:
+        _check_block_lists(P, W, H, focal, kw)
+    finally:
+        _lib.set_variant("CULL", 1)
+
+
+def _check_block_lists(P, W, H, focal, kw):
+    import torch
+
     from based_on_point_cloud_partitions_amd import rasterizer as rz
 
     g, cam = scene(P, W, H, focal, seed=5, **kw)

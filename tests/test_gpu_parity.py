@@ -17,6 +17,18 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["culled", "reference"])
+def tile_list_mode(request):
+    """Every test of this file runs twice: with the default tile lists (instances the splat cannot reach are left out, GSR_CULL=1)
+    and with the reference's lists (GSR_CULL=0: sort keys, point_list, ranges and n_contrib bit for bit)."""
+    from based_on_point_cloud_partitions_amd import _lib
+
+    _lib.set_variant("CULL", 1 if request.param == "culled" else 0)
+    yield request.param
+    _lib.set_variant("CULL", 1)
+
+
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -62,10 +74,15 @@ def test_snapshot_scene_against_committed_golden():
     assert np.array_equal(ex["tiles_touched"].view(np.uint32), fx["tiles_touched"])
     vis = fx["radii"] > 0
     assert np.array_equal(ex["depths"].view(np.uint32)[vis], fx["depth_bits"][vis])
-    assert np.array_equal(h(ex["keys_sorted"].view(np.uint64)), fx["h_keys_sorted"])
-    assert np.array_equal(h(ex["point_list"].view(np.uint32)), fx["h_point_list"])
-    assert np.array_equal(ex["ranges"].view(np.uint32), fx["ranges"])
-    assert np.array_equal(ex["n_contrib"].view(np.uint32), fx["n_contrib"])
+    from helpers import reference_lists
+    if reference_lists():
+        assert np.array_equal(h(ex["keys_sorted"].view(np.uint64)), fx["h_keys_sorted"])
+        assert np.array_equal(h(ex["point_list"].view(np.uint32)), fx["h_point_list"])
+        assert np.array_equal(ex["ranges"].view(np.uint32), fx["ranges"])
+        assert np.array_equal(ex["n_contrib"].view(np.uint32), fx["n_contrib"])
+    else:  # a subset of the fixture's lists: every tile's list is no longer than the fixture's
+        got, ref = ex["ranges"].view(np.uint32).reshape(-1, 2).astype(np.int64), fx["ranges"].astype(np.int64).reshape(-1, 2)
+        assert np.all(got[:, 1] - got[:, 0] <= ref[:, 1] - ref[:, 0])
     assert np.array_equal(ctx["color"].cpu().numpy(), fx["out_color"])
     assert np.array_equal(ex["final_T"], fx["final_T"])
     dL = np.random.default_rng(9).standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
@@ -219,12 +236,16 @@ def test_config2_500k_1080p_full_parity():
     st, ctx = _fwd_bwd(P=500_000, W=1920, H=1080, focal=1200.0, seed=0, n_cams=16, cam_index=0)
     assert st["num_rendered"] > 3_000_000
     # size-independent properties on the device results
+    from helpers import reference_lists
+
     ex = ctx["ex"]
-    keys = ex["keys_sorted"].cpu().numpy().view(np.uint64)
-    assert np.all(keys[1:] >= keys[:-1])
     r = ex["ranges"].cpu().numpy().view(np.uint32)
     ne = r[r[:, 1] > r[:, 0]]
-    assert ne[0, 0] == 0 and ne[-1, 1] == ctx["R"] and np.all(ne[1:, 0] == ne[:-1, 1])
+    listed = int(ne[-1, 1])  # instances in the lists: all R of them, or those the splats can reach (culled lists)
+    assert listed == ctx["R"] if reference_lists() else 0.3 * ctx["R"] < listed < ctx["R"]
+    assert ne[0, 0] == 0 and np.all(ne[1:, 0] == ne[:-1, 1])
+    keys = ex["keys_sorted"].cpu().numpy().view(np.uint64)[:listed]
+    assert np.all(keys[1:] >= keys[:-1])
     assert int(ex["tiles_touched"].cpu().numpy().view(np.uint32).astype(np.int64).sum()) == ctx["R"]
 
 
