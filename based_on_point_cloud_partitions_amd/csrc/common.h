@@ -463,6 +463,37 @@ __device__ __forceinline__ unsigned long long gsr_reach_mask(float mx, float my,
     return mask & all;
 }
 
+// The same question one level down: which of the four 8x8 quadrants of the tile whose first pixel is (x0, y0) can the splat's
+// alpha >= 1/255 ellipse reach?  Bit q = 2 * (y half) + (x half) -- the pixel block of wave q of the blend kernels.  Two bands
+// of 8 pixel rows, each cut like a tile row in gsr_reach_mask; conservative in the same way (NaN anywhere: bit set).
+__device__ __forceinline__ uint32_t gsr_quad_mask(float mx, float my, float cx, float cy, float cz, float opacity, float x0, float y0)
+{
+    if (!(opacity > 0.f)) return 15u;
+    float t = 2.0f * __logf(255.0f * opacity);
+    t = t + (2e-3f * fabsf(t) + 5e-3f);
+    if (t < 0.f) return 0u;
+    const float det = cx * cz - cy * cy;
+    if (!(cx > 0.f) || !(cz > 0.f) || !(det > 0.f) || !(det < INFINITY)) return 15u;
+    const float inv_cx = __builtin_amdgcn_rcpf(cx), inv_det = __builtin_amdgcn_rcpf(det);
+    const float vmax = __builtin_amdgcn_sqrtf(cx * t * inv_det) * 1.001f + 0.02f;
+    const float vstar = -(cy * __builtin_amdgcn_rcpf(cz)) * __builtin_amdgcn_sqrtf(cz * t * inv_det);
+    const float slope = -cy * inv_cx;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int band = 0; band < 2; band++) {
+        const float vl = y0 + (float)(8 * band) - my, vh = vl + 7.0f;
+        if (vl > vmax || vh < -vmax) continue;
+        const float vr = fminf(fmaxf(vstar, vl), vh), vq = fminf(fmaxf(-vstar, vl), vh);
+        const float dr = fmaxf(cx * t - det * vr * vr, 0.f), dq = fmaxf(cx * t - det * vq * vq, 0.f);
+        const float ur = slope * vr + __builtin_amdgcn_sqrtf(dr) * inv_cx, ul = slope * vq - __builtin_amdgcn_sqrtf(dq) * inv_cx;
+        const float m = 0.02f + 1e-3f * (fabsf(ur) + fabsf(ul));
+        const float A = mx + ul - m, B = mx + ur + m;  // pixel centres the band's cut of the ellipse spans
+        if (!(A > x0 + 7.0f) && !(B < x0)) mask |= 1u << (2 * band);
+        if (!(A > x0 + 15.0f) && !(B < x0 + 8.0f)) mask |= 2u << (2 * band);
+    }
+    return mask;
+}
+
 // auxiliary.h:46-56 -- tile rectangle of a splat (saturating float->int as the hardware converts)
 __device__ __forceinline__ void gsr_get_rect(float px, float py, int max_radius, int gx, int gy,
                                              uint32_t& minx, uint32_t& miny, uint32_t& maxx, uint32_t& maxy)

@@ -19,7 +19,7 @@
 
 namespace {
 
-template <bool LISTS>
+template <bool LISTS, bool QUAD>
 __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, int gy, int wave8x8, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list,
@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     __shared__ uint32_t s_slot[LISTS ? 256 : 1];  // instance slot (emission order) of the staged entry
     __shared__ int s_done[4];
     __shared__ int s_wcnt[4];    // entries each wave keeps after the tile-level rejection
+    __shared__ unsigned long long s_qm[QUAD ? 4 : 1][4];  // QUAD: per blend wave (quadrant), per staging wave: the staged entries that can reach it
 
     // 1-D launch in `order` (tiles by descending list length, binning.hip); NULL = row-major
     const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;
@@ -62,7 +63,87 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     float px = inside ? pixf_x : PARKED;
     bool wave_done = !gsr_any(px != PARKED);
 
-    for (int i = 0; i < rounds; i++) {
+    if (QUAD && tid < 4) {  // padding entries that can never pass the range test (the walk takes entries four at a time)
+        s_a[256 + tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
+        s_b[256 + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
+    }
+    for (int i = 0; QUAD && i < rounds; i++) {
+        // QUAD: every staged entry is tested against the four 8x8 quadrants of the tile (gsr_quad_mask) and stays at its staged
+        // position; a wave walks only the entries that can reach ITS block, picking them from the ballot masks with scalar bit
+        // scans -- 40 % of the (entry, wave) visits of a walk over the whole tile list blend nothing.
+        const int progress = i * 256 + tid;
+        uint32_t qm = 0;
+        float4 q0, q1, q2;
+        uint32_t id = 0;
+        if (progress < total) {
+            id = point_list[r0 + progress];
+            const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+            qm = gsr_quad_mask(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0);
+            if (wave8x8 == 2 && qm) qm = 15u;  // debugging aid (GSR_QUAD=2): every kept entry visits every wave
+        }
+        const unsigned long long b0 = __ballot(qm & 1u), b1 = __ballot(qm & 2u), b2 = __ballot(qm & 4u), b3 = __ballot(qm & 8u);
+        __syncthreads();  // previous batch fully consumed
+        if (lane == 0) { s_done[wave] = wave_done; s_qm[0][wave] = b0; s_qm[1][wave] = b1; s_qm[2][wave] = b2; s_qm[3][wave] = b3; }
+        if (qm != 0u) {
+            // conservative skip threshold on `power` (see header); opacity <= 0 or NaN never skips; clamped to -80 (see below)
+            const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
+            s_a[tid] = q0;
+            s_b[tid] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress));
+            s_c[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
+        }
+        __syncthreads();
+        // workgroup-wide early exit (forward.cu:301-304)
+        if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
+        if (wave_done) continue;
+        for (int w = 0; w < 4 && !wave_done; w++) {
+            unsigned long long m = s_qm[wave][w];
+            // (readfirstlane returns int: without the uint32_t casts the low half would be sign-extended over the high half)
+            m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
+                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
+            while (m != 0ull) {
+                // the next (up to) four entries of this wave; missing ones are the padding entry
+                int jj[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    jj[u] = m != 0ull ? 64 * w + (int)__builtin_ctzll(m) : 256 + u;
+                    m &= m - 1ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = jj[u];
+                    const float4 a = s_a[j];
+                    const float4 b = s_b[j];
+                    const float dx = a.x - px, dy = a.y - pixf_y;
+                    // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
+                    const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
+                    const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
+                    const bool maybe = power >= b.z;
+                    if (gsr_any(maybe)) {  // wave-uniform
+                        if (maybe && px != PARKED && power <= 0.0f) {
+                            const float alpha = fminf(0.99f, b.y * gsr_expf_inrange(power));
+                            if (alpha >= 1.0f / 255.0f) {
+                                const float test_T = T * (1.0f - alpha);
+                                if (test_T < 0.0001f) {
+                                    px = PARKED;  // done
+                                } else {
+                                    const float4 c = s_c[j];
+                                    // CONTRACT-FMA: C += (f*alpha)*T
+                                    C0 = __builtin_fmaf(c.x * alpha, T, C0);
+                                    C1 = __builtin_fmaf(c.y * alpha, T, C1);
+                                    C2 = __builtin_fmaf(c.z * alpha, T, C2);
+                                    T = test_T;
+                                    last_contributor = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
+                                }
+                            }
+                        }
+                    }
+                }
+                if (!gsr_any(px != PARKED)) { wave_done = true; break; }
+            }
+        }
+    }
+    for (int i = 0; !QUAD && i < rounds; i++) {
         // gather this batch's records and decide, per entry, whether the tile can see it at all
         const int progress = i * 256 + tid;
         bool keep = false;
@@ -221,9 +302,12 @@ void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint3
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int wave8x8 = gsr_variant("WAVE8X8", 1);
     if (blist && wave8x8)  // the block lists are per 8x8 block = per wave of the 8x8 layout
-        hipLaunchKernelGGL(render_forward_kernel<true>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
+        hipLaunchKernelGGL((render_forward_kernel<true, false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
                            final_T, n_contrib, out_color, blist, bcount, bmask);
+    else if (wave8x8 && gsr_variant("QUAD", 1))
+        hipLaunchKernelGGL((render_forward_kernel<false, true>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, gsr_variant("QUAD", 1) == 2 ? 2 : 1, order, ranges, point_list, splat, bg,
+                           final_T, n_contrib, out_color, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(render_forward_kernel<false>, dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
+        hipLaunchKernelGGL((render_forward_kernel<false, false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
                            final_T, n_contrib, out_color, nullptr, nullptr, nullptr);
 }
