@@ -117,7 +117,7 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
 
 constexpr int NV = 9;  // partial sums per list entry
 
-template <int BATCH, bool RS, bool FAST_EXP>
+template <int BATCH, bool RS, bool FAST_EXP, bool QUAD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) render_backward_kernel(int W, int H, int gx, int gy, int wave8x8, const uint32_t* __restrict__ order,
                                                               const uint32_t* __restrict__ ranges,
                                                               const uint32_t* __restrict__ point_list,
@@ -131,6 +131,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
     __shared__ float4 s_b[BATCH];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
     __shared__ float4 s_c[BATCH];  // r, g, b, gradient row index (uint bits)
     __shared__ int s_wcnt[4];      // entries each wave keeps after the tile-level rejection
+    // QUAD: per blend wave (quadrant), per 64 staged entries: the entries that can reach the wave's 8x8 block (gsr_quad_mask);
+    // entries stay at their staged position and a wave picks its own with scalar bit scans (as in the forward)
+    __shared__ unsigned long long s_qm[QUAD ? 4 : 1][(BATCH + 63) / 64];
     __shared__ __attribute__((aligned(16))) float s_acc[4 * ACC_STRIDE];
     __shared__ uint32_t s_max[4];
 
@@ -211,17 +214,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
                 }
             }
         }
+        int nb = 0;
+        if constexpr (QUAD) {
+            uint32_t qm = 0;
+            if (keep) {
+                qm = gsr_quad_mask(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0);
+                if (qm == 0u) {  // owns a row, but no block of the tile can reach it (the two tests round differently): zero row
+                    float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    o[0] = z; o[1] = z; o[2] = z;
+                }
+            }
+            const unsigned long long b0 = __ballot(qm & 1u), b1 = __ballot(qm & 2u), b2 = __ballot(qm & 4u), b3 = __ballot(qm & 8u);
+            __syncthreads();  // previous batch fully flushed
+            if (lane == 0 && wave < (BATCH + 63) / 64) { s_qm[0][wave] = b0; s_qm[1][wave] = b1; s_qm[2][wave] = b2; s_qm[3][wave] = b3; }
+            if (tid < BATCH) {
+                if (qm != 0u) {
+                    s_a[tid] = q0;
+                    s_b[tid] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float(k));  // clamp: see the forward
+                }
+                s_c[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(qm != 0u ? row : 0xFFFFFFFFu));  // 0xFFFFFFFF: nothing to flush
+            }
+        } else {
         const unsigned long long bal = __ballot(keep);
         if (lane == 0) s_wcnt[wave] = __popcll(bal);
         __syncthreads();  // previous batch fully flushed; counts visible
         int base = 0;
         for (int w = 0; w < wave; w++) base += s_wcnt[w];
-        const int nb = __builtin_amdgcn_readfirstlane(s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
+        nb = __builtin_amdgcn_readfirstlane(s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
         if (keep) {  // order-preserving compaction
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
             s_a[pos] = q0;
             s_b[pos] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float(k));  // clamp: see the forward
             s_c[pos] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(row));
+        }
         }
         {   // zero this wave's accumulators
             float4* z = reinterpret_cast<float4*>(my_acc);
@@ -230,8 +256,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
                 if (t * 64 + lane < ACC_STRIDE / 4) z[t * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-#pragma unroll 2
-        for (int j = 0; j < nb; j++) {
+        auto walk_entry = [&](const int j) {
             const float4 a = s_a[j];
             const float4 b = s_b[j];
             const uint32_t kidx = __float_as_uint(b.w);  // position of this entry in the tile's list
@@ -247,7 +272,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
             // the mask directly.  Written with bools, the compiler re-materialises every combined predicate through
             // v_cndmask + v_cmp_ne (two half-rate VALU instructions per test).
             const unsigned long long m_maybe = m_act & __builtin_amdgcn_ballot_w64(power >= b.z);  // power > 0 is tested below
-            if (m_maybe == 0ull) continue;  // wave-uniform
+            if (m_maybe == 0ull) return;  // wave-uniform
             unsigned long long m_c = m_maybe & __builtin_amdgcn_ballot_w64(power <= 0.0f);
             // G = exp(power) from the hardware exp2 (v_exp_f32, <= 1e-6 relative off gsr_expf on the range that can pass),
             // 2 issue slots instead of the 17 instructions of the forward's fully specified gsr_expf.  The alpha >= 1/255
@@ -260,7 +285,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
                 alpha = fminf(0.99f, b.y * G);
             }
             m_c &= __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
-            if (m_c == 0ull) continue;  // wave-uniform
+            if (m_c == 0ull) return;  // wave-uniform
             // From here all 64 lanes run the same straight-line code.  A lane that does not contribute is given alpha = G = 0:
             // then T/(1-0) = T, its gradient terms vanish, and the colour recurrence (backward.cu:515) leaves accum unchanged
             // (0 * c + 1 * accum) -- so no per-variable select is needed.
@@ -295,10 +320,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
                     o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5; o[6] = v6; o[7] = v7; o[8] = v8;
                 }
             }
+        };
+        if constexpr (QUAD) {
+#pragma unroll
+            for (int w = 0; w < (BATCH + 63) / 64; w++) {
+                unsigned long long m = s_qm[wave][w];
+                m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
+                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
+                while (m != 0ull) {
+                    walk_entry(64 * w + (int)__builtin_ctzll(m));
+                    m &= m - 1ull;
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int j = 0; j < nb; j++) walk_entry(j);
         }
         __syncthreads();
         // flush: entry `tid` of the batch -> one 48-byte row, waves summed in fixed order
-        if (tid < nb) {
+        if (QUAD ? (tid < BATCH && __float_as_uint(s_c[tid].w) != 0xFFFFFFFFu) : (tid < nb)) {
             float r[NV];
 #pragma unroll
             for (int t = 0; t < NV; t++) {
@@ -349,14 +389,16 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
     if (!gsr_variant("LPT", 1)) order = nullptr;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int batch = gsr_variant("BWD_BATCH", 128), rs = gsr_variant("BWD_RS", 1), wave8x8 = gsr_variant("WAVE8X8", 1);
-#define GSR_BWD_LAUNCH(B, R_, F_)                                                                                               \
-    hipLaunchKernelGGL((render_backward_kernel<B, R_, F_>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, \
+#define GSR_BWD_LAUNCH(B, R_, F_, Q_)                                                                                           \
+    hipLaunchKernelGGL((render_backward_kernel<B, R_, F_, Q_>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, \
                        bg, final_T, n_contrib, dL_dpix, grad_rows)
     const int fast = gsr_variant("BWD_FASTEXP", 1);
-    if (batch == 256) GSR_BWD_LAUNCH(256, true, true);
-    else if (batch == 64) GSR_BWD_LAUNCH(64, true, true);
-    else if (!rs) GSR_BWD_LAUNCH(128, false, false);
-    else if (fast) GSR_BWD_LAUNCH(128, true, true);
-    else GSR_BWD_LAUNCH(128, true, false);
+    const bool quad = wave8x8 && gsr_variant("QUAD", 1);
+    if (batch == 256) GSR_BWD_LAUNCH(256, true, true, false);
+    else if (batch == 64) GSR_BWD_LAUNCH(64, true, true, false);
+    else if (!rs) GSR_BWD_LAUNCH(128, false, false, false);
+    else if (fast && quad) GSR_BWD_LAUNCH(128, true, true, true);
+    else if (fast) GSR_BWD_LAUNCH(128, true, true, false);
+    else GSR_BWD_LAUNCH(128, true, false, false);
 #undef GSR_BWD_LAUNCH
 }
