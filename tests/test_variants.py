@@ -1,0 +1,49 @@
+"""The experiment switches of DESIGN.md §4 (environment GSR_<NAME>, gsr_set_variant) select alternative kernels for A/B
+measurements; none may change a result beyond the documented bars.  One mid-size scene through every alternative, against the
+oracle: forward bit-exact (lists in the mode the switch combination builds), gradients within 1e-4."""
+import numpy as np
+import pytest
+
+from helpers import assert_forward_bit_exact, assert_grads_close, hip_backward_raw, hip_forward_raw, oracle_forward, scene
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+DEFAULTS = dict(QUAD=1, CULL=1, BIN=2, LPT=1, MAILBOX=1, BWD_RS=1, BWD_FASTEXP=1, BWD_BATCH=128, KEYS=0, WAVE8X8=1, EARLY=1, BANDS=8,
+                GB_BLOCK=128, BLK=0)
+ALTERNATIVES = [
+    dict(QUAD=0),                 # every wave walks the whole tile list
+    dict(QUAD=0, CULL=0),         # ... over the reference's lists
+    dict(BIN=1),                  # whole-image slices instead of bands (culled lists)
+    dict(BIN=0),                  # 64-bit radix sort as the reference (reference lists by construction)
+    dict(LPT=0),                  # row-major tile launch
+    dict(MAILBOX=0),              # num_rendered through memcpy + stream sync
+    dict(EARLY=0),                # no early launch of the binning head
+    dict(BWD_RS=0),               # butterfly wave reduction in the backward
+    dict(BWD_FASTEXP=0),          # gs_expf in the backward
+    dict(BWD_BATCH=64), dict(BWD_BATCH=256),
+    dict(KEYS=1),                 # sorted keys written during the forward
+    dict(WAVE8X8=0),              # 16x4 pixel strips per wave
+    dict(BANDS=16),
+    dict(GB_BLOCK=256),
+]
+
+
+@pytest.mark.parametrize("alt", ALTERNATIVES, ids=lambda a: ",".join(f"{k}={v}" for k, v in a.items()))
+def test_alternative_kernels_keep_the_results(alt):
+    from based_on_point_cloud_partitions_amd import _lib
+
+    g, cam = scene(12000, 330, 250, 210.0, seed=23, scale_lo=0.008, scale_hi=0.12)
+    bg = (0.1, 0.6, 0.2)
+    st = oracle_forward(g, cam, bg=bg)
+    dL = np.random.default_rng(8).standard_normal((3, 250, 330)).astype(np.float32)
+    want = oracle.backward(st, dL)
+    try:
+        for k, v in alt.items():
+            _lib.set_variant(k, v)
+        ctx = hip_forward_raw(g, cam, bg=bg)
+        assert_forward_bit_exact(ctx, st)
+        assert_grads_close(hip_backward_raw(ctx, dL), want)
+    finally:
+        for k in alt:
+            _lib.set_variant(k, DEFAULTS[k])
