@@ -443,13 +443,43 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr a, uint32_t n, uint32_t N
     __syncthreads();
 }
 
-// (5a) one workgroup per tile, lists of up to BUCKET_CAP entries (the common case): bucket sort in LDS.
+// The same network driven by one wave alone (tile_sort_tiny_kernel's degenerate lists): a wave's LDS operations execute in
+// order, so no barrier is needed between stages.
+__device__ __forceinline__ void bitonic_sort_wave(unsigned long long* a, uint32_t n, uint32_t N)
+{
+    const uint32_t half = N >> 1, lane = threadIdx.x & 63;
+    for (uint32_t k = 2, lk = 1; k <= N; k <<= 1, lk++) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t i = lane; i < half; i += 64) {
+            const uint32_t blk = i >> (lk - 1), off = i & (hk - 1);
+            const uint32_t lo = (blk << lk) + off, hi = (blk << lk) + k - 1 - off;
+            if (hi < n) {
+                const unsigned long long x = a[lo], y = a[hi];
+                if (x > y) { a[lo] = y; a[hi] = x; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = k >> 2, lj = lk - 2; j >= 1; j >>= 1, lj--) {
+            for (uint32_t i = lane; i < half; i += 64) {
+                const uint32_t lo = ((i >> lj) << (lj + 1)) + (i & (j - 1)), hi = lo + j;
+                if (hi < n) {
+                    const unsigned long long x = a[lo], y = a[hi];
+                    if (x > y) { a[lo] = y; a[hi] = x; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Bucket sort of one tile's list in LDS (by a workgroup, or by one wave: THREADS == 64).
 // Depth bits are mapped monotonically onto N buckets (N = pow2 >= n, so ~1 entry per bucket), a counting sort places
-// the keys bucket by bucket, and each thread finishes a few adjacent buckets with an insertion sort on the full 64-bit
-// (depth, id) key.  ~10 LDS operations per entry instead of the ~100 of a bitonic network (which is what limited the
-// first version: it was LDS-bandwidth bound).  A bucket that grows past BUCKET_LIMIT (many equal depths) sends the
-// tile to the bitonic path, so the worst case stays n log^2 n.
-constexpr int BUCKET_CAP = 2048;      // lists sorted by a 256-thread workgroup (tile_sort_small_kernel)
+// the keys bucket by bucket, and every entry then ranks itself against the few keys of its own bucket on the full 64-bit
+// (depth, id) key and is written straight to its final position.  ~10 LDS operations per entry instead of the ~100 of a
+// bitonic network (which is what limited the first version: it was LDS-bandwidth bound).  A bucket that grows past
+// BUCKET_LIMIT (many equal depths) sends the tile to the bitonic path, so the worst case stays n log^2 n.
+constexpr int BUCKET_CAP = 2048;      // lists sorted by a 256-thread workgroup of tile_sort_small_kernel
+constexpr int BUCKET_CAP_TINY = 512;  // lists of fewer entries than this are sorted by a single wave of it
 constexpr int BUCKET_CAP_MID = 8192;  // lists sorted by a 1024-thread workgroup (tile_sort_mid_kernel)
 constexpr int BUCKET_LIMIT = 16;
 template <int CAP, int THREADS>
@@ -462,6 +492,19 @@ struct BucketSortLds {
 };
 
 // BUCKET_EPT = entries (and buckets) per thread: 2, 4 or 8 for lists of up to 2, 4 or 8 x THREADS entries
+// barrier of the group that sorts one list: the workgroup, or a single wave (whose LDS operations execute in order: only the
+// compiler has to be kept from moving them)
+template <int THREADS>
+__device__ __forceinline__ void bucket_sync()
+{
+    if constexpr (THREADS == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int BUCKET_EPT, int THREADS, int CAP>
 __device__ __forceinline__ void bucket_sort_tile(BucketSortLds<CAP, THREADS>& L, uint32_t tile, uint32_t r0, uint32_t n, uint32_t N,
                                                  const unsigned long long* __restrict__ bins, uint32_t* __restrict__ point_list,
@@ -472,7 +515,8 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds<CAP, THREADS>& L,
     uint32_t* s_red = L.red;
     uint32_t* s_wsum = L.wsum;
     int& s_overflow = L.overflow;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // THREADS == 64: one wave of a larger workgroup sorts the list on its own (tid = lane, barriers at wave scope)
+    const int tid = THREADS == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long* seg = bins + r0;
     unsigned long long key[BUCKET_EPT];
     uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
@@ -491,7 +535,7 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds<CAP, THREADS>& L,
     if (lane == 0) { s_red[wave] = dmin; s_red[WAVES + wave] = dmax; }
     for (uint32_t b = tid; b <= N; b += THREADS) s_cnt[b] = 0;
     if (tid == 0) s_overflow = 0;
-    __syncthreads();
+    bucket_sync<THREADS>();
 #pragma unroll
     for (int w = 0; w < WAVES; w++) { dmin = min(dmin, s_red[w]); dmax = max(dmax, s_red[WAVES + w]); }
     // monotone map depth bits -> bucket (float rounding is monotone, so equal or larger depth never gets a smaller bucket)
@@ -507,7 +551,7 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds<CAP, THREADS>& L,
             atomicAdd(&s_cnt[bucket[e]], 1u);
         }
     }
-    __syncthreads();
+    bucket_sync<THREADS>();
     // exclusive scan of the N bucket counts: thread t owns buckets [t*EPT, t*EPT + EPT)
     uint32_t c[BUCKET_EPT], tsum = 0;
 #pragma unroll
@@ -523,71 +567,110 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds<CAP, THREADS>& L,
         if (lane >= off) incl += u;
     }
     if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
+    bucket_sync<THREADS>();
     uint32_t start = incl - tsum;
     for (int w = 0; w < wave; w++) start += s_wsum[w];
-    uint32_t bstart[BUCKET_EPT];
     bool big = false;
 #pragma unroll
     for (int e = 0; e < BUCKET_EPT; e++) {
         const uint32_t b = tid * BUCKET_EPT + e;
-        bstart[e] = start;
         if (b < N) s_cnt[b] = start;  // becomes the bucket's write cursor
         start += c[e];
         big |= c[e] > BUCKET_LIMIT;
     }
     if (big) s_overflow = 1;
-    __syncthreads();
+    bucket_sync<THREADS>();
     if (s_overflow) {
         // degenerate depth distribution: sort the whole list with the bitonic network instead
-        __syncthreads();
+        bucket_sync<THREADS>();
 #pragma unroll
         for (int e = 0; e < BUCKET_EPT; e++) {
             const uint32_t i = tid + THREADS * e;
             if (i < n) s_keys[i] = key[e];
         }
-        __syncthreads();
-        if (n > 1) bitonic_sort_block<true>(s_keys, n, N);
-    } else {
-#pragma unroll
-        for (int e = 0; e < BUCKET_EPT; e++) {
-            const uint32_t i = tid + THREADS * e;
-            if (i < n) s_keys[atomicAdd(&s_cnt[bucket[e]], 1u)] = key[e];
+        bucket_sync<THREADS>();
+        if (n > 1) {
+            if constexpr (THREADS == 64) bitonic_sort_wave(s_keys, n, N);
+            else bitonic_sort_block<true>(s_keys, n, N);
         }
-        __syncthreads();
-        // insertion sort of this thread's buckets (adjacent, so the union [bstart[0], end) is one contiguous run)
-        const uint32_t lo = bstart[0], hi = start;
-        for (uint32_t i = lo + 1; i < hi; i++) {
-            const unsigned long long x = s_keys[i];
-            uint32_t j = i;
-            while (j > lo && s_keys[j - 1] > x) { s_keys[j] = s_keys[j - 1]; j--; }
-            s_keys[j] = x;
+        for (uint32_t i = tid; i < n; i += THREADS) {
+            const unsigned long long k = s_keys[i];
+            point_list[r0 + i] = (uint32_t)k;
+            if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
         }
-        __syncthreads();
+        return;
     }
-    for (uint32_t i = tid; i < n; i += THREADS) {
-        const unsigned long long k = s_keys[i];
-        point_list[r0 + i] = (uint32_t)k;
-        if (keys_sorted) keys_sorted[r0 + i] = ((unsigned long long)tile << 32) | (k >> 32);
+#pragma unroll
+    for (int e = 0; e < BUCKET_EPT; e++) {
+        const uint32_t i = tid + THREADS * e;
+        if (i < n) s_keys[atomicAdd(&s_cnt[bucket[e]], 1u)] = key[e];
+    }
+    bucket_sync<THREADS>();
+    // every entry ranks itself inside its bucket (the cursors now hold the bucket ends; keys are unique, the id is part of
+    // them) and goes straight to its place in the list: balanced over the entries, no dependent chain of LDS round trips as
+    // in a per-thread insertion sort, and no second pass over the sorted keys
+#pragma unroll
+    for (int e = 0; e < BUCKET_EPT; e++) {
+        const uint32_t i = tid + THREADS * e;
+        if (i < n) {
+            const uint32_t b = bucket[e];
+            const uint32_t st = b ? s_cnt[b - 1] : 0u, en = s_cnt[b];
+            uint32_t rank = st;
+            for (uint32_t j = st; j < en; j++) rank += s_keys[j] < key[e] ? 1u : 0u;
+            point_list[r0 + rank] = (uint32_t)key[e];
+            if (keys_sorted) keys_sorted[r0 + rank] = ((unsigned long long)tile << 32) | (key[e] >> 32);
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) tile_sort_small_kernel(const uint32_t* __restrict__ ranges,
+// (5a) lists of up to BUCKET_CAP entries, one launch, two kinds of workgroup:
+//  * workgroups [0, n_long): a 256-thread workgroup per list of BUCKET_CAP_TINY..BUCKET_CAP entries, striding over the front of
+//    `order` (descending length class of 8 entries; BUCKET_CAP_TINY is a class boundary) until the first shorter list;
+//  * the others: ONE wave per list of fewer than BUCKET_CAP_TINY entries (tile = 4 * (workgroup - n_long) + wave) -- most tiles
+//    of the 500k-Gaussian configuration (mean 280).  A whole workgroup per short list spent its time waiting (ranges -> bins
+//    -> four workgroup barriers -> store); a wave per list keeps four times as many lists in flight and needs no barrier.
+// The long lists are dispatched first and sort while the short ones stream through the rest of the chip.
+union TileSortLds {
+    BucketSortLds<BUCKET_CAP, 256> whole;
+    BucketSortLds<BUCKET_CAP_TINY, 64> wave[4];
+};
+
+__global__ void __launch_bounds__(256) tile_sort_small_kernel(int T, int n_long, const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ ranges,
                                                               const unsigned long long* __restrict__ bins,
                                                               uint32_t* __restrict__ point_list,
                                                               unsigned long long* __restrict__ keys_sorted)
 {
-    __shared__ BucketSortLds<BUCKET_CAP, 256> L;
-    const uint32_t tile = blockIdx.x;
+    __shared__ TileSortLds L;
+    if ((int)blockIdx.x < n_long) {
+        for (int i = blockIdx.x; i < T; i += n_long) {
+            const uint32_t tile = order[i];
+            const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+            const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
+            const uint32_t n = r1 - r0;
+            if (n < BUCKET_CAP_TINY) break;
+            if (n > BUCKET_CAP) continue;  // tile_sort_mid_kernel's
+            uint32_t N = 1;
+            while (N < n) N <<= 1;
+            if (N <= 512) bucket_sort_tile<2, 256, BUCKET_CAP>(L.whole, tile, r0, n, N, bins, point_list, keys_sorted);
+            else if (N <= 1024) bucket_sort_tile<4, 256, BUCKET_CAP>(L.whole, tile, r0, n, N, bins, point_list, keys_sorted);
+            else bucket_sort_tile<8, 256, BUCKET_CAP>(L.whole, tile, r0, n, N, bins, point_list, keys_sorted);
+            __syncthreads();  // the LDS image is reused by the next list
+        }
+        return;
+    }
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = 4u * (blockIdx.x - (uint32_t)n_long) + wv;
+    if (tile >= (uint32_t)T) return;
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
     const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const uint32_t n = r1 - r0;
-    if (n == 0 || n > BUCKET_CAP) return;  // empty, or handled by tile_sort_mid_kernel
+    if (n == 0 || n >= BUCKET_CAP_TINY) return;
     uint32_t N = 1;
     while (N < n) N <<= 1;
-    if (N <= 512) bucket_sort_tile<2, 256, BUCKET_CAP>(L, tile, r0, n, N, bins, point_list, keys_sorted);
-    else if (N <= 1024) bucket_sort_tile<4, 256, BUCKET_CAP>(L, tile, r0, n, N, bins, point_list, keys_sorted);
-    else bucket_sort_tile<8, 256, BUCKET_CAP>(L, tile, r0, n, N, bins, point_list, keys_sorted);
+    if (N <= 128) bucket_sort_tile<2, 64, BUCKET_CAP_TINY>(L.wave[wv], tile, r0, n, N, bins, point_list, keys_sorted);
+    else if (N <= 256) bucket_sort_tile<4, 64, BUCKET_CAP_TINY>(L.wave[wv], tile, r0, n, N, bins, point_list, keys_sorted);
+    else bucket_sort_tile<8, 64, BUCKET_CAP_TINY>(L.wave[wv], tile, r0, n, N, bins, point_list, keys_sorted);
 }
 
 // (5a') lists of more than 2048 entries: up to 8192 (dense scenes: the 2M-Gaussian configuration has a mean list length of ~1900): the same
@@ -721,8 +804,9 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
         hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, G.cull, splat, table, totals, ranges,
                            order, reinterpret_cast<uint2*>(bins));
     }
-    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(T), dim3(256), 0, s, ranges, reinterpret_cast<const unsigned long long*>(bins),
-                       point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
+    const int n_long = T < 1024 ? T : 1024;
+    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(n_long + (T + 3) / 4), dim3(256), 0, s, T, n_long, order, ranges,
+                       reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
     hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, order, ranges,
                        reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
 }
