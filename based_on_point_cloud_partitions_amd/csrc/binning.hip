@@ -21,6 +21,49 @@
 namespace {
 
 constexpr int TCHUNK = 16384;       // tiles histogrammed per pass (64 KB of LDS counters)
+constexpr int BUCKET_CAP = 2048;      // lists sorted by a 256-thread workgroup of tile_sort_small_kernel
+constexpr int BUCKET_CAP_TINY = 512;  // lists of fewer entries than this are sorted by a single wave of it
+constexpr int BUCKET_CAP_MID = 8192;  // lists sorted by a 1024-thread workgroup (tile_sort_mid_kernel)
+
+// The valid lanes of the wave that hold the same 8-bit class as this lane (meaningless for an invalid lane).  Neighbouring tiles
+// have similar list lengths, so a plain LDS atomic per tile on its length-class counter serialises on a few hot counters: the
+// first lane of each group adds the group's size instead.
+__device__ __forceinline__ unsigned long long class_peers(uint32_t cls, bool valid)
+{
+    const unsigned long long v = __ballot(valid);
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+        const uint32_t set = (cls >> bit) & 1u;
+        const unsigned long long bal = __ballot(set != 0u);
+        const uint32_t keep = set - 1u;  // 0 if this lane has the bit (keep the lanes of `bal`), ~0 if not (keep the others)
+        lo &= (uint32_t)bal ^ keep;
+        hi &= (uint32_t)(bal >> 32) ^ keep;
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void class_count(uint32_t total, bool valid, uint32_t* s_cls)
+{
+    const uint32_t cls = min(total >> 3, 255u);  // length class: 8 entries per class up to 2040, everything longer in the top class
+    const unsigned long long peers = class_peers(cls, valid);
+    if (valid && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(peers)) atomicAdd(&s_cls[cls], (uint32_t)__builtin_popcountll(peers));
+}
+
+// Lists of BUCKET_CAP_TINY..BUCKET_CAP entries ("long" lists: a 256-thread workgroup sorts them, not a wave) and longer ones ("mid":
+// a 1024-thread workgroup) are announced to the sort kernels by the scatter kernels, which hold the tile totals: one segment of
+// tile ids per band behind order[] (common.h GSR_LONG_* / GSR_MID_*), no global atomics.  list_append: aggregated append of
+// this lane's tile to the workgroup's list, one LDS atomic per wave.
+__device__ __forceinline__ void list_append(bool is_long, uint32_t tile, uint32_t* s_count, uint32_t* __restrict__ list)
+{
+    const unsigned long long m = __ballot(is_long);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(s_count, (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+    if (is_long) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = tile;
+}
 
 struct SliceRect {
     uint32_t mnx, mny, mxx, mxy, dbits;
@@ -118,10 +161,7 @@ __global__ void __launch_bounds__(256) tile_colscan_kernel(int T, int nslices, u
 // Every workgroup first turns the tile totals into the tiles' start offsets itself (an exclusive scan of T numbers costs a
 // 1024-thread workgroup about a microsecond; a separate single-workgroup kernel for it was 11 us of serialised latency on the
 // critical path).  Workgroup 0 also stores the reference's ranges[] (uint2 per tile; empty tiles stay (0,0) like
-// identifyTileRanges after its memset); workgroup 1 also emits order[], the tile ids by descending list length (256 length
-// classes, counting sort): the blend kernels take workgroup b -> tile order[b], so the long lists start first and the
-// short ones fill the tail of the launch (longest-processing-time-first).  Which tile a workgroup renders has no effect
-// on any result.
+// identifyTileRanges after its memset); workgroup 1 also announces the long lists to the sort kernels (list_append).
 __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int gpb, int gx, int gy, int T, int cull, const float* __restrict__ splat,
                                                            const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
                                                            uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
@@ -129,29 +169,22 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int 
 {
     extern __shared__ uint32_t s_cur[];
     __shared__ uint32_t wtot[16];
-    __shared__ uint32_t cls_cnt[256];
+    __shared__ uint32_t s_nlong[2], s_cls[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == (gridDim.x > 1 ? 1u : 0u)) {
-        if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
+    if (blockIdx.x == (gridDim.x > 1 ? 1u : 0u)) {  // the long lists (one segment for the whole image here)
+        if (threadIdx.x < 2) s_nlong[threadIdx.x] = 0;
+        if (threadIdx.x < 256) s_cls[threadIdx.x] = 0;
         __syncthreads();
-        // length class: 8 entries per class up to 2040, everything longer in the top class
-        for (int i = threadIdx.x; i < T; i += SLICE_THREADS) atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u);
-        __syncthreads();
-        if (threadIdx.x < 64) {  // exclusive scan from the top class down (one wave, 4 classes per lane)
-            const int c0 = 255 - 4 * (int)threadIdx.x;
-            const uint32_t n0 = cls_cnt[c0], n1 = cls_cnt[c0 - 1], n2 = cls_cnt[c0 - 2], n3 = cls_cnt[c0 - 3];
-            const uint32_t tsum = n0 + n1 + n2 + n3;
-            uint32_t incl = tsum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t u = __shfl_up(incl, off, 64);
-                if ((int)threadIdx.x >= off) incl += u;
-            }
-            const uint32_t b = incl - tsum;
-            cls_cnt[c0] = b; cls_cnt[c0 - 1] = b + n0; cls_cnt[c0 - 2] = b + n0 + n1; cls_cnt[c0 - 3] = b + n0 + n1 + n2;
+        for (int base = 0; base < T; base += SLICE_THREADS) {
+            const int i = base + (int)threadIdx.x;
+            const uint32_t n = i < T ? totals[i] : 0u;
+            class_count(n, i < T, s_cls);
+            list_append(n >= (uint32_t)BUCKET_CAP_TINY && n <= (uint32_t)BUCKET_CAP, (uint32_t)i, &s_nlong[0], order + GSR_LONG_LIST(T));
+            list_append(n > (uint32_t)BUCKET_CAP, (uint32_t)i, &s_nlong[1], order + GSR_MID_LIST(T));
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < T; i += SLICE_THREADS) order[atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u)] = (uint32_t)i;
+        if (threadIdx.x == 0) { order[GSR_LONG_COUNT(T)] = s_nlong[0]; order[GSR_MID_COUNT(T)] = s_nlong[1]; }
+        if (threadIdx.x < 256) order[GSR_CLASS_HIST(T) + threadIdx.x] = s_cls[threadIdx.x];
     }
     const int first = blockIdx.x * gpb, last = min(P, first + gpb);
     uint32_t chunk_base = 0;  // instances in the tiles before this chunk
@@ -316,77 +349,73 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_banded_kernel(int 
                                                                              uint2* __restrict__ bins)
 {
     extern __shared__ uint32_t s_cur[];
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t cls_cnt[256];
+    __shared__ uint32_t wtot[16], woth[16];
+    __shared__ uint32_t s_nlong[2], s_cls[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int T = G.T;
-    if (blockIdx.x == (uint32_t)(G.nb * BAND_SLICES)) {  // one extra workgroup: launch order of the blend kernels (see tile_scatter_kernel)
-        if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < T; i += SLICE_THREADS) atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u);
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int c0 = 255 - 4 * (int)threadIdx.x;
-            const uint32_t n0 = cls_cnt[c0], n1 = cls_cnt[c0 - 1], n2 = cls_cnt[c0 - 2], n3 = cls_cnt[c0 - 3];
-            const uint32_t tsum = n0 + n1 + n2 + n3;
-            uint32_t incl = tsum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t u = __shfl_up(incl, off, 64);
-                if ((int)threadIdx.x >= off) incl += u;
-            }
-            const uint32_t bb = incl - tsum;
-            cls_cnt[c0] = bb; cls_cnt[c0 - 1] = bb + n0; cls_cnt[c0 - 2] = bb + n0 + n1; cls_cnt[c0 - 3] = bb + n0 + n1 + n2;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < T; i += SLICE_THREADS) order[atomicAdd(&cls_cnt[min(totals[i] >> 3, 255u)], 1u)] = (uint32_t)i;
-        return;
-    }
     const int b = blockIdx.x / BAND_SLICES, sidx = blockIdx.x % BAND_SLICES;
     const uint32_t row0 = (uint32_t)(b * G.bh), row1 = min((uint32_t)G.gy, row0 + (uint32_t)G.bh);
     const int t0 = (int)row0 * G.gx, tn = (int)(row1 - row0) * G.gx;
     const uint32_t* row = table + (size_t)blockIdx.x * G.tmax;
-    // exclusive scan of ALL tile totals (tile starts); the band's tiles get their cursor, workgroup 0 stores ranges[]
-    constexpr int EPT = 8;
+    // this thread's first Gaussian: its loads (id -> record) are in flight during the prologue
+    uint32_t first, last;
+    band_slice_range(band_count, b, sidx, first, last);
+    uint32_t i = first + threadIdx.x;
+    bool have = i < last;
+    uint32_t idx = have ? band_list[(size_t)b * P + i] : 0u;
+    SliceRect r{};
+    if (have) r = load_rect(splat, (int)idx, G.gx, G.gy, G.cull);
+    // tile starts = instances in the bands before this one + exclusive scan of the band's own tile totals (one load round trip:
+    // scanning all T totals in every workgroup, with the table row read behind the scan, cost 12 us of the kernel's 44);
+    // slice 0 of the band stores them as the reference's ranges[] (empty tiles (0,0) like identifyTileRanges after its memset)
+    // and announces the band's long lists to the sort kernels (list_append)
+    uint32_t other = 0;
+    for (int k = threadIdx.x; k < t0; k += SLICE_THREADS) other += totals[k];
+    if (threadIdx.x < 2) s_nlong[threadIdx.x] = 0;
+    if (sidx == 0 && threadIdx.x < 256) s_cls[threadIdx.x] = 0;
     uint32_t chunk_base = 0;
-    for (int tbase = 0; tbase < T; tbase += SLICE_THREADS * EPT) {
-        const int i0 = tbase + (int)threadIdx.x * EPT;
-        uint32_t v[EPT], tsum = 0;
-#pragma unroll
-        for (int e = 0; e < EPT; e++) { v[e] = i0 + e < T ? totals[i0 + e] : 0u; tsum += v[e]; }
-        uint32_t incl = tsum;
+    for (int tbase = 0; tbase < tn; tbase += SLICE_THREADS) {
+        const int lt = tbase + (int)threadIdx.x;
+        const bool in = lt < tn;
+        const uint32_t v = in ? totals[t0 + lt] : 0u, rw = in ? row[lt] : 0u;
+        uint32_t incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t u = __shfl_up(incl, off, 64);
             if (lane >= off) incl += u;
         }
-        if (lane == 63) wtot[wave] = incl;
+        if (tbase == 0) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) other += __shfl_xor(other, off, 64);
+        }
+        if (lane == 63) { wtot[wave] = incl; if (tbase == 0) woth[wave] = other; }
         __syncthreads();
         uint32_t wbase = 0, chunk_total = 0;
 #pragma unroll
-        for (int w = 0; w < SLICE_THREADS / 64; w++) { if (w < wave) wbase += wtot[w]; chunk_total += wtot[w]; }
-        uint32_t st = chunk_base + wbase + incl - tsum;
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const int t = i0 + e;
-            if (t < T) {
-                const int lt = t - t0;
-                if (lt >= 0 && lt < tn) s_cur[lt] = st + row[lt];
-                if (blockIdx.x == 0) {
-                    ranges[2 * t] = v[e] ? st : 0u;
-                    ranges[2 * t + 1] = v[e] ? st + v[e] : 0u;
-                }
+        for (int w = 0; w < SLICE_THREADS / 64; w++) {
+            if (w < wave) wbase += wtot[w];
+            chunk_total += wtot[w];
+            if (tbase == 0) chunk_base += woth[w];
+        }
+        const uint32_t st = chunk_base + wbase + incl - v;
+        if (in) {
+            s_cur[lt] = st + rw;
+            if (sidx == 0) {
+                ranges[2 * (t0 + lt)] = v ? st : 0u;
+                ranges[2 * (t0 + lt) + 1] = v ? st + v : 0u;
             }
-            st += v[e];
+        }
+        if (sidx == 0) {
+            class_count(v, in, s_cls);
+            list_append(v >= (uint32_t)BUCKET_CAP_TINY && v <= (uint32_t)BUCKET_CAP, (uint32_t)(t0 + lt), &s_nlong[0], order + GSR_LONG_LIST(T) + t0);
+            list_append(v > (uint32_t)BUCKET_CAP, (uint32_t)(t0 + lt), &s_nlong[1], order + GSR_MID_LIST(T) + t0);
         }
         chunk_base += chunk_total;
         __syncthreads();
     }
-    uint32_t first, last;
-    band_slice_range(band_count, b, sidx, first, last);
-    for (uint32_t i = first + threadIdx.x; i < last; i += SLICE_THREADS) {
-        const uint32_t idx = band_list[(size_t)b * P + i];
-        const SliceRect r = load_rect(splat, (int)idx, G.gx, G.gy, G.cull);
+    if (sidx == 0 && threadIdx.x == 0) { order[GSR_LONG_COUNT(T) + b] = s_nlong[0]; order[GSR_MID_COUNT(T) + b] = s_nlong[1]; }
+    if (sidx == 0 && threadIdx.x < 256) order[GSR_CLASS_HIST(T) + b * 256 + threadIdx.x] = s_cls[threadIdx.x];
+    while (have) {
         const uint32_t y0 = max(r.mny, row0), y1 = min(r.mxy, row1);
         for (uint32_t y = y0; y < y1; y++)
             for (uint32_t x = r.mnx; x < r.mxx; x++) {
@@ -394,6 +423,12 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_banded_kernel(int 
                 const uint32_t slot = atomicAdd(&s_cur[(y - row0) * (uint32_t)G.gx + x], 1u);
                 bins[slot] = make_uint2(idx, r.dbits);  // little-endian u64 = depth << 32 | id
             }
+        i += SLICE_THREADS;
+        have = i < last;
+        if (have) {
+            idx = band_list[(size_t)b * P + i];
+            r = load_rect(splat, (int)idx, G.gx, G.gy, G.cull);
+        }
     }
 }
 
@@ -478,9 +513,6 @@ __device__ __forceinline__ void bitonic_sort_wave(unsigned long long* a, uint32_
 // (depth, id) key and is written straight to its final position.  ~10 LDS operations per entry instead of the ~100 of a
 // bitonic network (which is what limited the first version: it was LDS-bandwidth bound).  A bucket that grows past
 // BUCKET_LIMIT (many equal depths) sends the tile to the bitonic path, so the worst case stays n log^2 n.
-constexpr int BUCKET_CAP = 2048;      // lists sorted by a 256-thread workgroup of tile_sort_small_kernel
-constexpr int BUCKET_CAP_TINY = 512;  // lists of fewer entries than this are sorted by a single wave of it
-constexpr int BUCKET_CAP_MID = 8192;  // lists sorted by a 1024-thread workgroup (tile_sort_mid_kernel)
 constexpr int BUCKET_LIMIT = 16;
 template <int CAP, int THREADS>
 struct BucketSortLds {
@@ -623,33 +655,119 @@ __device__ __forceinline__ void bucket_sort_tile(BucketSortLds<CAP, THREADS>& L,
     }
 }
 
-// (5a) lists of up to BUCKET_CAP entries, one launch, two kinds of workgroup:
-//  * workgroups [0, n_long): a 256-thread workgroup per list of BUCKET_CAP_TINY..BUCKET_CAP entries, striding over the front of
-//    `order` (descending length class of 8 entries; BUCKET_CAP_TINY is a class boundary) until the first shorter list;
-//  * the others: ONE wave per list of fewer than BUCKET_CAP_TINY entries (tile = 4 * (workgroup - n_long) + wave) -- most tiles
-//    of the 500k-Gaussian configuration (mean 280).  A whole workgroup per short list spent its time waiting (ranges -> bins
-//    -> four workgroup barriers -> store); a wave per list keeps four times as many lists in flight and needs no barrier.
+// Launch order of the blend kernels: order[] = the tile ids by descending list length (256 length classes of 8 entries,
+// everything from 2040 up in the top class; counting sort): the blend kernels take workgroup b -> tile order[b], so the long
+// lists start first and the short ones fill the tail of the launch (longest-processing-time-first).  Which tile a workgroup
+// renders has no effect on any result.  The counting half is done by the scatter kernels (class_count, per band), the placing
+// half by the first workgroups of tile_sort_small_kernel, one per band, beside the sorting.  Neighbouring tiles have similar
+// lengths, so a wave first groups its lanes by class (8 ballots) and only the first lane of a group touches the LDS counter:
+// a plain atomic per tile serialises on a few hot counters.
+// One 256-thread workgroup per band places the band's tiles [t0, t0 + tn): the per-band class counts (scatter kernels) give the
+// start of every class in order[] and the number of tiles the bands before this one put into it.
+__device__ __forceinline__ void emit_band_order(int T, int nbl, int band, int t0, int tn, const uint32_t* __restrict__ ranges,
+                                                uint32_t* __restrict__ order, uint32_t* cls_cur)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint2* rg = reinterpret_cast<const uint2*>(ranges) + t0;
+    constexpr int CH = 4;  // tiles per thread whose ranges are loaded together (one round trip, then the ballots)
+    uint2 q[CH];
+#pragma unroll
+    for (int e = 0; e < CH; e++) {
+        const int i = e * 256 + (int)threadIdx.x;
+        q[e] = i < tn ? rg[i] : make_uint2(0u, 0u);
+    }
+    uint32_t total = 0, before = 0;
+    for (int b = 0; b < nbl; b++) {
+        const uint32_t h = order[GSR_CLASS_HIST(T) + b * 256 + threadIdx.x];
+        total += h;
+        if (b < band) before += h;
+    }
+    cls_cur[threadIdx.x] = total;
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan from the top class down (one wave, 4 classes per lane)
+        const int c0 = 255 - 4 * (int)threadIdx.x;
+        const uint32_t n0 = cls_cur[c0], n1 = cls_cur[c0 - 1], n2 = cls_cur[c0 - 2], n3 = cls_cur[c0 - 3];
+        const uint32_t tsum = n0 + n1 + n2 + n3;
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += u;
+        }
+        const uint32_t b = incl - tsum;
+        cls_cur[c0] = b; cls_cur[c0 - 1] = b + n0; cls_cur[c0 - 2] = b + n0 + n1; cls_cur[c0 - 3] = b + n0 + n1 + n2;
+    }
+    __syncthreads();
+    cls_cur[threadIdx.x] += before;
+    __syncthreads();
+    for (int base = 0; base < tn; base += 256 * CH) {
+        if (base) {
+#pragma unroll
+            for (int e = 0; e < CH; e++) {
+                const int i = base + e * 256 + (int)threadIdx.x;
+                q[e] = i < tn ? rg[i] : make_uint2(0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < CH; e++) {
+            const int i = base + e * 256 + (int)threadIdx.x;
+            if (base + e * 256 >= tn) break;  // uniform
+            const bool valid = i < tn;
+            const uint32_t cls = min((q[e].y - q[e].x) >> 3, 255u);
+            const unsigned long long peers = class_peers(cls, valid);
+            const int leader = valid ? __builtin_ctzll(peers) : (int)lane;
+            uint32_t slot = 0;
+            if (valid && (int)lane == leader) slot = atomicAdd(&cls_cur[cls], (uint32_t)__builtin_popcountll(peers));
+            slot = (uint32_t)__shfl((int)slot, leader, 64);
+            if (valid) order[slot + (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull))] = (uint32_t)(t0 + i);
+        }
+    }
+}
+
+// k-th tile of the per-band lists taken together (counts[nbl], band segments `seg` tiles apart); false past the end
+__device__ __forceinline__ bool listed_tile(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists, int nbl, int seg, uint32_t k,
+                                            uint32_t& tile)
+{
+    for (int band = 0; band < nbl; band++) {
+        const uint32_t c = counts[band];
+        if (k < c) { tile = lists[(size_t)band * seg + k]; return true; }
+        k -= c;
+    }
+    return false;
+}
+
+// (5a) lists of up to BUCKET_CAP entries, one launch, three kinds of workgroup:
+//  * workgroups [0, nbl): emit_band_order;
+//  * the next n_long: a 256-thread workgroup per list of BUCKET_CAP_TINY..BUCKET_CAP entries, striding over the long
+//    lists of the bands (list_append; `nbl` segments `seg` tiles apart, n_long is a multiple of nbl);
+//  * the others: ONE wave per list of fewer than BUCKET_CAP_TINY entries (tile = 4 * (workgroup - nbl - n_long) + wave) -- most
+//    tiles of the 500k-Gaussian configuration (mean 280).  A whole workgroup per short list spent its time waiting (ranges ->
+//    bins -> four workgroup barriers -> store); a wave per list keeps four times as many lists in flight and needs no barrier.
 // The long lists are dispatched first and sort while the short ones stream through the rest of the chip.
 union TileSortLds {
     BucketSortLds<BUCKET_CAP, 256> whole;
     BucketSortLds<BUCKET_CAP_TINY, 64> wave[4];
 };
 
-__global__ void __launch_bounds__(256) tile_sort_small_kernel(int T, int n_long, const uint32_t* __restrict__ order,
+__global__ void __launch_bounds__(256) tile_sort_small_kernel(int T, int n_long, int nbl, int seg, uint32_t* __restrict__ order,
                                                               const uint32_t* __restrict__ ranges,
                                                               const unsigned long long* __restrict__ bins,
                                                               uint32_t* __restrict__ point_list,
                                                               unsigned long long* __restrict__ keys_sorted)
 {
     __shared__ TileSortLds L;
-    if ((int)blockIdx.x < n_long) {
-        for (int i = blockIdx.x; i < T; i += n_long) {
-            const uint32_t tile = order[i];
+    if ((int)blockIdx.x < nbl) {
+        const int t0 = (int)blockIdx.x * seg;
+        emit_band_order(T, nbl, (int)blockIdx.x, t0, nbl == 1 ? T : min(seg, T - t0), ranges, order, L.whole.cnt);
+        return;
+    }
+    if ((int)blockIdx.x < nbl + n_long) {
+        for (uint32_t k = blockIdx.x - (uint32_t)nbl;; k += (uint32_t)n_long) {
+            uint32_t tile;
+            if (!listed_tile(order + GSR_LONG_COUNT(T), order + GSR_LONG_LIST(T), nbl, seg, k, tile)) break;
             const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
             const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
             const uint32_t n = r1 - r0;
-            if (n < BUCKET_CAP_TINY) break;
-            if (n > BUCKET_CAP) continue;  // tile_sort_mid_kernel's
             uint32_t N = 1;
             while (N < n) N <<= 1;
             if (N <= 512) bucket_sort_tile<2, 256, BUCKET_CAP>(L.whole, tile, r0, n, N, bins, point_list, keys_sorted);
@@ -660,7 +778,7 @@ __global__ void __launch_bounds__(256) tile_sort_small_kernel(int T, int n_long,
         return;
     }
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = 4u * (blockIdx.x - (uint32_t)n_long) + wv;
+    const uint32_t tile = 4u * (blockIdx.x - (uint32_t)(nbl + n_long)) + wv;
     if (tile >= (uint32_t)T) return;
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
     const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
@@ -675,33 +793,30 @@ __global__ void __launch_bounds__(256) tile_sort_small_kernel(int T, int n_long,
 
 // (5a') lists of more than 2048 entries: up to 8192 (dense scenes: the 2M-Gaussian configuration has a mean list length of ~1900): the same
 // bucket sort with 1024 threads and 96 KB of LDS; the bitonic network took 0.8 ms per frame there.
-__global__ void __launch_bounds__(1024) tile_sort_mid_kernel(int T, const uint32_t* __restrict__ order,
+__global__ void __launch_bounds__(1024) tile_sort_mid_kernel(int T, int nbl, int seg, uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
                                                              const unsigned long long* bins,
                                                              uint32_t* __restrict__ point_list,
                                                              unsigned long long* __restrict__ keys_sorted)
 {
     __shared__ BucketSortLds<BUCKET_CAP_MID, 1024> L;
-    // `order` lists the tiles by descending length class and every list of 2040+ entries is in its first class, so the
-    // workgroups stride over the front of `order` and stop at the first shorter list (no launch of T mostly idle workgroups)
-    for (int i = blockIdx.x; i < T; i += gridDim.x) {
-        const uint32_t tile = order[i];
+    for (uint32_t k = blockIdx.x;; k += gridDim.x) {
+        uint32_t tile;
+        if (!listed_tile(order + GSR_MID_COUNT(T), order + GSR_MID_LIST(T), nbl, seg, k, tile)) break;
         const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
         const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
         const uint32_t n = r1 - r0;
-        if (n < 2040) break;
-        if (n <= BUCKET_CAP) continue;
         uint32_t N = 1;
         while (N < n) N <<= 1;
         if (n > BUCKET_CAP_MID) {
             // rare: list longer than the LDS budget -> normalized bitonic network in place in HBM (workgroup-scope visibility
             // via __syncthreads; the network keeps waves 0-3 busy, the others only join the barriers)
-            unsigned long long* seg = const_cast<unsigned long long*>(bins) + r0;
-            bitonic_sort_block<false>(seg, n, N);
-            for (uint32_t k = threadIdx.x; k < n; k += 1024) {
-                const unsigned long long key = seg[k];
-                point_list[r0 + k] = (uint32_t)key;
-                if (keys_sorted) keys_sorted[r0 + k] = ((unsigned long long)tile << 32) | (key >> 32);
+            unsigned long long* sg = const_cast<unsigned long long*>(bins) + r0;
+            bitonic_sort_block<false>(sg, n, N);
+            for (uint32_t q = threadIdx.x; q < n; q += 1024) {
+                const unsigned long long key = sg[q];
+                point_list[r0 + q] = (uint32_t)key;
+                if (keys_sorted) keys_sorted[r0 + q] = ((unsigned long long)tile << 32) | (key >> 32);
             }
         } else if (N <= 4096) bucket_sort_tile<4, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
         else bucket_sort_tile<8, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
@@ -795,7 +910,7 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
     if (band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_)) {
         const uint32_t* band_count = band_mem;
         const uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
-        hipLaunchKernelGGL(tile_scatter_banded_kernel, dim3(G.nb * BAND_SLICES + 1), dim3(SLICE_THREADS), (size_t)G.tmax * 4, s, P, G, splat,
+        hipLaunchKernelGGL(tile_scatter_banded_kernel, dim3(G.nb * BAND_SLICES), dim3(SLICE_THREADS), (size_t)G.tmax * 4, s, P, G, splat,
                            band_count, band_list, table, totals, ranges, order, reinterpret_cast<uint2*>(bins));
     } else {
         int gpb;
@@ -804,9 +919,12 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
         hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, G.cull, splat, table, totals, ranges,
                            order, reinterpret_cast<uint2*>(bins));
     }
+    // long-list segments: one per band (banded scatter) or one for the image
+    const bool banded = band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_);
+    const int nbl = banded ? G.nb : 1, seg = banded ? G.tmax : 0;
     const int n_long = T < 1024 ? T : 1024;
-    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(n_long + (T + 3) / 4), dim3(256), 0, s, T, n_long, order, ranges,
+    hipLaunchKernelGGL(tile_sort_small_kernel, dim3(nbl + n_long + (T + 3) / 4), dim3(256), 0, s, T, n_long, nbl, seg, order, ranges,
                        reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
-    hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, order, ranges,
+    hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, nbl, seg, order, ranges,
                        reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
 }

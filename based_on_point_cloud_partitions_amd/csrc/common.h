@@ -35,6 +35,17 @@ struct GeomLayout {
 struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
 };
+#define GSR_BAND_COUNTERS 64  // band_mem = [64 counters][nb * P ids]
+// order[] = [T tile ids by descending list length][64 + 64 counts, one per band, of the tiles whose lists a workgroup sorts
+// ("long") and of those only the 1024-thread kernel can sort ("mid")][T + T tile ids: those tiles, the segment of a band at
+// its first tile id] (binning.hip)
+#define GSR_LONG_COUNT(T) (T)
+#define GSR_MID_COUNT(T) ((T) + GSR_BAND_COUNTERS)
+#define GSR_LONG_LIST(T) ((T) + 2 * GSR_BAND_COUNTERS)
+#define GSR_MID_LIST(T) (2 * (T) + 2 * GSR_BAND_COUNTERS)
+// ... followed by [64 bands][256 length classes]: tiles of the band per class (the band's share of the counting sort behind order[])
+#define GSR_CLASS_HIST(T) (3 * (T) + 2 * GSR_BAND_COUNTERS)
+
 struct BinLayout {
     size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, band, fixed_bytes, bytes;
     // per-8x8-block lists written by the forward blend for the backward (render_backward_skew.hip): blist = uint2 {Gaussian id,
@@ -104,7 +115,7 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
         if (gsr_band_table_bytes(W, H) > tb) tb = gsr_band_table_bytes(W, H);
         L.table = o; o = gsr_align(o + tb);
         L.totals = o; o = gsr_align(o + t * 4);
-        L.order = o; o = gsr_align(o + t * 4);  // tiles by descending list length: launch order of the blend kernels
+        L.order = o; o = gsr_align(o + (3 * t + 2 * GSR_BAND_COUNTERS + 256 * GSR_BAND_COUNTERS) * 4);  // tiles by descending list length (launch order of the blend kernels) + the long lists
         L.band = o; o = gsr_align(o + gsr_band_list_bytes(P, W, H));  // band counters + per-band Gaussian id lists
     }
     L.hist_global = o; o = gsr_align(o + 8 * 256 * 4);
@@ -160,7 +171,6 @@ void gsr_launch_scan_blocks2(int nblocks, const uint32_t* block_sums, uint32_t* 
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
                      uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint64_t* keys, uint32_t* vals,
                      uint32_t* band_mem, hipStream_t s);
-#define GSR_BAND_COUNTERS 64  // band_mem = [64 counters][nb * P ids]
 // true (and the band count / height in tile rows) when the banded tile binning applies to this tile grid
 bool gsr_band_geometry(int gx, int gy, int* nb, int* bh);
 // returns 0 if the sorted pairs end in (ka,va), 1 if in (kb,vb)
