@@ -45,7 +45,11 @@ struct GaussBackwardPtrs {
 // RAW (gsr_backward_params): scales / rotations are the pre-activation parameters; the chain rule through exp / sigmoid /
 // normalize is applied here and dL/dSH leaves LDS as the two tensors dL/dfeatures_dc, dL/dfeatures_rest -- the autograd
 // passes of scene/gaussian_model.py:102-122 (exp, sigmoid, normalize, cat backward) never touch HBM.
-template <bool RAW, int BS>
+// DIRECT (degree-3 storage, 16 coefficients, activated parameters): a visible Gaussian reads its 192-byte SH row with twelve
+// 16-byte loads at the start of its chain and stores its dL/dSH row the same way -- no SH tile in LDS, so the workgroup's LDS is
+// the small gradient-row buffer alone and twice as many waves are in flight (the kernel is latency-bound: with half the waves
+// it takes 1.5x as long).  Culled Gaussians read no SH at all.
+template <bool RAW, int BS, bool DIRECT>
 __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
 {
     extern __shared__ float s_tile[];  // [BS][3M + 1]
@@ -120,11 +124,17 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     if (RAW) {
         sh_cols_load(a.features_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
         if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
-    } else if (a.has_shs) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
-    __syncthreads();
-    float* __restrict__ my_row = s_tile + threadIdx.x * stride;  // SH in, dL/dSH out
+    } else if (!DIRECT && a.has_shs) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
+    if (!DIRECT) __syncthreads();
+    float shr[DIRECT ? 48 : 1];
+    float* __restrict__ my_row = s_tile + threadIdx.x * stride;  // SH in, dL/dSH out (not DIRECT)
+    // DIRECT: dL/dSH = basis weight x dL/dRGB, zero for a culled Gaussian; the rows leave through LDS after the chain (below)
+    float w[DIRECT ? 16 : 1], dRGBo[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (DIRECT ? 16 : 1); i++) w[i] = 0.f;
 
     if (visible) {
+
     float* __restrict__ o_m2 = a.dL_dmeans2D + 3 * (size_t)idx;
     float* __restrict__ o_col = a.dL_dcolors + 3 * (size_t)idx;
     float* __restrict__ o_m3 = a.dL_dmeans3D + 3 * (size_t)idx;
@@ -228,13 +238,21 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     dmean_y += (proj[4] * m_w - proj[7] * mul1) * dL_dmean2D_x + (proj[5] * m_w - proj[7] * mul2) * dL_dmean2D_y;
     dmean_z += (proj[8] * m_w - proj[11] * mul1) * dL_dmean2D_x + (proj[9] * m_w - proj[11] * mul2) * dL_dmean2D_y;
 
-    if (a.has_shs) {
+    if (DIRECT || a.has_shs) {
         // computeColorFromSH backward (backward.cu:20-139)
+        if (DIRECT) {
+            const float4* row_in = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                const float4 t = row_in[q];
+                shr[4 * q] = t.x; shr[4 * q + 1] = t.y; shr[4 * q + 2] = t.z; shr[4 * q + 3] = t.w;
+            }
+        }
         const int deg = a.D;
         const float dox = mx - a.campos[0], doy = my - a.campos[1], doz = mz - a.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
-        const float* sh = my_row;
+        const float* sh = DIRECT ? shr : my_row;
         float dRGB[3];
         for (int ch = 0; ch < 3; ch++) dRGB[ch] = dL_dcol[ch] * (a.clamped[3 * idx + ch] ? 0.f : 1.f);
         float dx_[3] = {0, 0, 0}, dy_[3] = {0, 0, 0}, dz_[3] = {0, 0, 0};
@@ -270,6 +288,24 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
                 }
             }
         }
+        if (DIRECT) {
+            // dL/dSH = dRGB/dSH * dL/dRGB: the 16 basis weights (zero above the active degree)
+            dRGBo[0] = dRGB[0]; dRGBo[1] = dRGB[1]; dRGBo[2] = dRGB[2];
+            w[0] = bSH_C0;
+            if (deg > 0) {
+                w[1] = -bSH_C1 * y; w[2] = bSH_C1 * z; w[3] = -bSH_C1 * x;
+                if (deg > 1) {
+                    w[4] = bSH_C2[0] * xy; w[5] = bSH_C2[1] * yz; w[6] = bSH_C2[2] * (2.f * zz - xx - yy);
+                    w[7] = bSH_C2[3] * xz; w[8] = bSH_C2[4] * (xx - yy);
+                    if (deg > 2) {
+                        w[9] = bSH_C3[0] * y * (3.f * xx - yy); w[10] = bSH_C3[1] * xy * z;
+                        w[11] = bSH_C3[2] * y * (4.f * zz - xx - yy); w[12] = bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                        w[13] = bSH_C3[4] * x * (4.f * zz - xx - yy); w[14] = bSH_C3[5] * z * (xx - yy);
+                        w[15] = bSH_C3[6] * x * (xx - 3.f * yy);
+                    }
+                }
+            }
+        } else {
         // then dL/dSH = dRGB/dSH * dL/dRGB into the same row
         OUT(0, bSH_C0);
         int written = 1;
@@ -291,7 +327,9 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
         }
 #undef SH
 #undef OUT
-        for (int i = 3 * written; i < 3 * M; i++) o_sh[i] = 0.f;  // coefficients above the active degree
+        if (!DIRECT)
+            for (int i = 3 * written; i < 3 * M; i++) o_sh[i] = 0.f;  // coefficients above the active degree
+        }
         const float ddx = dx_[0] * dRGB[0] + dx_[1] * dRGB[1] + dx_[2] * dRGB[2];
         const float ddy = dy_[0] * dRGB[0] + dy_[1] * dRGB[1] + dy_[2] * dRGB[2];
         const float ddz = dz_[0] * dRGB[0] + dz_[1] * dRGB[1] + dz_[2] * dRGB[2];
@@ -301,7 +339,7 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
         dmean_x += ((+sum2 - dox * dox) * ddx - doy * dox * ddy - doz * dox * ddz) * invsum32;
         dmean_y += (-dox * doy * ddx + (sum2 - doy * doy) * ddy - doz * doy * ddz) * invsum32;
         dmean_z += (-dox * doz * ddx - doy * doz * ddy + (sum2 - doz * doz) * ddz) * invsum32;
-    } else {
+    } else if (!DIRECT) {
         for (int i = 0; i < 3 * M; i++) o_sh[i] = 0.f;
     }
     o_m3[0] = dmean_x; o_m3[1] = dmean_y; o_m3[2] = dmean_z;
@@ -369,9 +407,28 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
         o_m3[0] = 0.f; o_m3[1] = 0.f; o_m3[2] = 0.f;
         if (!RAW || a.dL_dcov3D)
             for (int i = 0; i < 6; i++) o_cov[i] = 0.f;
-        for (int i = 0; i < n3; i++) my_row[i] = 0.f;
+        if (!DIRECT)
+            for (int i = 0; i < n3; i++) my_row[i] = 0.f;
         o_sc[0] = 0.f; o_sc[1] = 0.f; o_sc[2] = 0.f;
         reinterpret_cast<float4*>(a.dL_drots + 4 * (size_t)idx)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (DIRECT) {
+        // the dL/dSH rows in three pieces of 16 floats: products into an LDS tile of [BS][17] (the gradient-row buffer is free by
+        // now), out with coalesced 16-byte stores (64 contiguous bytes per row and piece)
+        float* g_out = a.dL_dsh + tile_base;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) s_tile[threadIdx.x * 17 + k] = w[(16 * c + k) / 3] * dRGBo[(16 * c + k) % 3];
+            __syncthreads();
+            for (int f = threadIdx.x; f < rows * 4; f += BS) {
+                const int r = f >> 2, q = f & 3;
+                const float* sp = s_tile + r * 17 + 4 * q;
+                *reinterpret_cast<float4*>(g_out + (size_t)r * 48 + 16 * c + 4 * q) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+            __syncthreads();
+        }
+        return;
     }
     __syncthreads();
     if (RAW) {
@@ -398,14 +455,20 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.P = a.P; p.D = a.D; p.M = a.M; p.has_shs = a.has_shs; p.has_scales = a.has_scales;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     const int bs = gsr_variant("GB_BLOCK", 128);
-    size_t lds = (size_t)bs * (3 * a.M + 1) * 4;
-    if (lds < (size_t)4 * bs * GSR_GROW_F * 4) lds = (size_t)4 * bs * GSR_GROW_F * 4;  // room for 4 gradient rows per Gaussian and chunk
+    const bool direct = !a.raw && a.has_shs && a.M == 16 && gsr_variant("GB_DIRECT", 1);
+    // LDS: the SH tile, or room for 4 (2 without the tile) gradient rows per Gaussian and chunk
+    size_t lds = direct ? (size_t)2 * bs * GSR_GROW_F * 4 : (size_t)bs * (3 * a.M + 1) * 4;
+    if (!direct && lds < (size_t)4 * bs * GSR_GROW_F * 4) lds = (size_t)4 * bs * GSR_GROW_F * 4;
     p.lds_floats = (int)(lds / 4);
+    lds += (size_t)gsr_variant("LDS_PAD", 0);
+    const dim3 grid((a.P + bs - 1) / bs), block(bs);
     if (bs == 256) {
-        if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256>), dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
-        else hipLaunchKernelGGL((gaussian_backward_kernel<false, 256>), dim3((a.P + 255) / 256), dim3(256), lds, s, p, h_x, h_y);
+        if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256, false>), grid, block, lds, s, p, h_x, h_y);
+        else if (direct) hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, true>), grid, block, lds, s, p, h_x, h_y);
+        else hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, false>), grid, block, lds, s, p, h_x, h_y);
     } else {
-        if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128>), dim3((a.P + 127) / 128), dim3(128), lds, s, p, h_x, h_y);
-        else hipLaunchKernelGGL((gaussian_backward_kernel<false, 128>), dim3((a.P + 127) / 128), dim3(128), lds, s, p, h_x, h_y);
+        if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128, false>), grid, block, lds, s, p, h_x, h_y);
+        else if (direct) hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, true>), grid, block, lds, s, p, h_x, h_y);
+        else hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, false>), grid, block, lds, s, p, h_x, h_y);
     }
 }

@@ -57,7 +57,7 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, const float* __restrict__ sh, F
 // Kernel-side copy of PreprocessArgs with __restrict__ pointers: lets the compiler hoist the input loads over the output
 // stores and read the camera matrices with scalar loads.
 struct PreprocessPtrs {
-    int P, D, M, W, H;
+    int P, D, M, W, H, sh_direct;
     const float* __restrict__ means3D; const float* __restrict__ scales; const float* __restrict__ rotations;
     const float* __restrict__ opacities; const float* __restrict__ shs; const float* __restrict__ cov3D_precomp;
     const float* __restrict__ colors_precomp; const float* __restrict__ viewmatrix; const float* __restrict__ projmatrix;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
         sh_cols_load(a.features_dc + (size_t)blockIdx.x * 256 * 3, s_sh, rows, 3, sh_stride, 0);
         if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * 256 * (n3 - 3), s_sh, rows, n3 - 3, sh_stride, 3);
         __syncthreads();
-    } else if (a.shs) {
+    } else if (a.shs && !a.sh_direct) {
         sh_tile_load(a.shs + (size_t)blockIdx.x * 256 * n3, s_sh, min(256, a.P - (int)blockIdx.x * 256), n3, sh_stride);
         __syncthreads();
     }
@@ -180,7 +180,21 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
                         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                         F3 dir{dx / len, dy / len, dz / len};
                         bool cl[3];
-                        const F3 c = sh_to_rgb(a.D, s_sh + threadIdx.x * sh_stride, dir, cl);
+                        F3 c;
+                        if (!RAW && a.sh_direct) {
+                            // degree 3, 16 coefficients: the visible Gaussian reads its own 192-byte row with twelve 16-byte loads (no
+                            // LDS tile, so nothing but registers limits the waves in flight; culled Gaussians read nothing)
+                            float sh[48];
+                            const float4* row = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
+#pragma unroll
+                            for (int q = 0; q < 12; q++) {
+                                const float4 v = row[q];
+                                sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
+                            }
+                            c = sh_to_rgb(3, sh, dir, cl);
+                        } else {
+                            c = sh_to_rgb(a.D, s_sh + threadIdx.x * sh_stride, dir, cl);
+                        }
                         cr = c.x; cg = c.y; cb = c.z;
                         a.clamped[3 * idx] = cl[0]; a.clamped[3 * idx + 1] = cl[1]; a.clamped[3 * idx + 2] = cl[2];
                     }
@@ -361,7 +375,8 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     p.radii = a.radii; p.splat = a.splat; p.cov3D = a.cov3D; p.clamped = a.clamped; p.tiles_touched = a.tiles_touched;
     p.block_sums = a.block_sums; p.row_block_sums = a.row_block_sums; p.features_dc = a.features_dc; p.features_rest = a.features_rest;
-    const size_t lds = (a.shs || a.raw) ? (size_t)256 * (3 * a.M + 1) * 4 : 0;
+    p.sh_direct = (!a.raw && a.shs && a.M == 16 && a.D == 3 && gsr_variant("PRE_DIRECT", 1)) ? 1 : 0;
+    const size_t lds = (((a.shs && !p.sh_direct) || a.raw) ? (size_t)256 * (3 * a.M + 1) * 4 : 0) + (size_t)gsr_variant("LDS_PAD", 0);
     if (a.raw)
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, focal_x, focal_y, gx, gy);
     else
