@@ -253,19 +253,28 @@ constexpr int NB_MAX = GSR_BAND_COUNTERS;  // bands
 
 struct BandGeom { int gx, gy, T, nb, bh, tmax, cull; };  // bh = tile rows per band, tmax = bh * gx; cull: see SliceRect::listed
 
+// PART_ITEMS Gaussians per thread: the one returning global atomic per band and workgroup on the eight band counters is what this
+// kernel waits for (~2.5 ns each, device-wide, whatever the address), so fewer, larger workgroups.
+constexpr int PART_ITEMS = 4;
 __global__ void __launch_bounds__(SLICE_THREADS) band_partition_kernel(int P, BandGeom G, const float* __restrict__ splat,
                                                                         uint32_t* __restrict__ band_count, uint32_t* __restrict__ band_list)
 {
     __shared__ uint32_t cnt[NB_MAX], base[NB_MAX];
     if (threadIdx.x < NB_MAX) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int idx = blockIdx.x * SLICE_THREADS + threadIdx.x;
-    int b0 = 0, b1 = -1;
-    if (idx < P) {
-        const SliceRect r = load_rect(splat, idx, G.gx, G.gy, 0);
-        if (r.visible && r.mxy > r.mny && r.mxx > r.mnx) { b0 = (int)r.mny / G.bh; b1 = (int)(r.mxy - 1) / G.bh; }
+    int b0[PART_ITEMS], b1[PART_ITEMS];
+#pragma unroll
+    for (int e = 0; e < PART_ITEMS; e++) {
+        const int idx = (blockIdx.x * PART_ITEMS + e) * SLICE_THREADS + threadIdx.x;
+        b0[e] = 0; b1[e] = -1;
+        if (idx < P) {
+            const SliceRect r = load_rect(splat, idx, G.gx, G.gy, 0);
+            if (r.visible && r.mxy > r.mny && r.mxx > r.mnx) { b0[e] = (int)r.mny / G.bh; b1[e] = (int)(r.mxy - 1) / G.bh; }
+        }
     }
-    for (int b = b0; b <= b1; b++) atomicAdd(&cnt[b], 1u);
+#pragma unroll
+    for (int e = 0; e < PART_ITEMS; e++)
+        for (int b = b0[e]; b <= b1[e]; b++) atomicAdd(&cnt[b], 1u);
     __syncthreads();
     if ((int)threadIdx.x < G.nb) {
         const uint32_t c = cnt[threadIdx.x];
@@ -273,7 +282,11 @@ __global__ void __launch_bounds__(SLICE_THREADS) band_partition_kernel(int P, Ba
         cnt[threadIdx.x] = 0;
     }
     __syncthreads();
-    for (int b = b0; b <= b1; b++) band_list[(size_t)b * P + base[b] + atomicAdd(&cnt[b], 1u)] = (uint32_t)idx;
+#pragma unroll
+    for (int e = 0; e < PART_ITEMS; e++) {
+        const int idx = (blockIdx.x * PART_ITEMS + e) * SLICE_THREADS + threadIdx.x;
+        for (int b = b0[e]; b <= b1[e]; b++) band_list[(size_t)b * P + base[b] + atomicAdd(&cnt[b], 1u)] = (uint32_t)idx;
+    }
 }
 
 __device__ __forceinline__ void band_slice_range(const uint32_t* __restrict__ band_count, int b, int sidx, uint32_t& first, uint32_t& last)
@@ -885,7 +898,7 @@ void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint3
         // the band counters were zeroed by emit_keys_kernel (preprocess.hip), which runs right before this stage
         uint32_t* band_count = band_mem;
         uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
-        hipLaunchKernelGGL(band_partition_kernel, dim3((P + SLICE_THREADS - 1) / SLICE_THREADS), dim3(SLICE_THREADS), 0, s, P, G, splat,
+        hipLaunchKernelGGL(band_partition_kernel, dim3((P + SLICE_THREADS * PART_ITEMS - 1) / (SLICE_THREADS * PART_ITEMS)), dim3(SLICE_THREADS), 0, s, P, G, splat,
                            band_count, band_list);
         hipLaunchKernelGGL(tile_count_banded_kernel, dim3(G.nb * BAND_SLICES), dim3(SLICE_THREADS), (size_t)G.tmax * 4, s, P, G, splat,
                            band_count, band_list, table);
