@@ -40,7 +40,13 @@ def main(d, out):
     w = load(f"{d}/write_counter_collection.csv", "WRITE_SIZE")
     res = collections.defaultdict(lambda: {"fetch_size_kib": 0.0, "write_size_kib": 0.0})
     launches_per_step = {"block_hist_kernel": 6, "bin_scan_kernel": 6, "scatter_kernel": 6}
+    # the LSD radix kernels also sort the Morton codes of the kNN initialisation (once per run): they belong to the step only
+    # when the step sorts with them (GSR_BIN=0), i.e. when no tile-binning kernel was launched
+    radix = ("global_hist_kernel", "block_hist_kernel", "bin_scan_kernel", "scatter_kernel")
+    binned = "tile_scatter_banded_kernel" in f or "tile_scatter_kernel" in f
     for k, st in STAGE.items():
+        if binned and k in radix:
+            continue
         mult = launches_per_step.get(k, 1)
         if k in f:
             res[st]["fetch_size_kib"] += f[k] * mult
@@ -51,6 +57,8 @@ def main(d, out):
     sq = {c: load(sqp, c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES")} if os.path.exists(sqp) else {}
     for c, per in sq.items():
         for k, st in STAGE.items():
+            if binned and k in radix:
+                continue
             if k in per:
                 res[st][c.lower()] = res[st].get(c.lower(), 0.0) + per[k] * launches_per_step.get(k, 1)
     outd = {}
