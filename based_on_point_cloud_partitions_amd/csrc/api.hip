@@ -239,7 +239,7 @@ static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_byte
     {
         StageTimer t(GSR_STAGE_SCAN, s);
         gsr_launch_scan_blocks2(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), a.row_block_sums,
-                                (uint32_t*)(g + L.row_block_offsets), w->mail ? mail_dev : nullptr, w->seq, s);
+                                (uint32_t*)(g + L.row_block_offsets), w->mail ? mail_dev : nullptr, w->seq, (uint32_t*)(g + L.band_count), s);
     }
     return 0;
 }
@@ -312,15 +312,19 @@ static void launch_render_head(int P, int W, int H, void* geom_buffer, void* bin
     const BinLayout B = gsr_bin_layout(0, P, W, H);  // the offsets used here do not depend on R
     char* g = (char*)geom_buffer;
     char* b = (char*)binning_buffer;
-    {   // per-Gaussian instance offsets only (needed by the backward's gradient-row addressing)
+    {   // per-Gaussian instance offsets (needed by the backward's gradient-row addressing), with the band partition when it applies
         StageTimer t(GSR_STAGE_EMIT, s);
-        gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched), (const uint32_t*)(g + G.block_offsets),
-                        (uint32_t*)(g + G.point_offsets), (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets), nullptr,
-                        nullptr, (uint32_t*)(b + B.band), s);
+        if (!gsr_launch_emit_partition(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
+                                       (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets),
+                                       (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets),
+                                       (uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), s))
+            gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched), (const uint32_t*)(g + G.block_offsets),
+                            (uint32_t*)(g + G.point_offsets), (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets),
+                            nullptr, nullptr, s);
     }
     StageTimer t(GSR_STAGE_SORT, s);
     gsr_launch_tile_binning_head(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
-                                 (uint32_t*)(b + B.band), s);
+                                 (const uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), s);
 }
 
 static bool can_launch_head_early(int P, int W, int H, const void* binning_buffer, size_t binning_bytes)
@@ -354,10 +358,15 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
         uint32_t* va = (uint32_t*)(b + B.vals_a);
         uint32_t* vb = (uint32_t*)(b + B.vals_b);
         if (gsr_variant("BIN", 1)) {
-            if (!head_done) launch_render_head(P, W, H, geom_buffer, binning_buffer, s);
+            if (!head_done) {
+                // the scan kernel zeroed the band counters for ONE head; this one may be a second (the early head ran, then the
+                // caller had to re-allocate the binning buffer and came back through gsr_forward_render)
+                hipMemsetAsync(g + G.band_count, 0, GSR_BAND_COUNTERS * 4, s);
+                launch_render_head(P, W, H, geom_buffer, binning_buffer, s);
+            }
             StageTimer t(GSR_STAGE_SORT, s, false);
             gsr_launch_tile_binning_tail(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
-                                         (uint32_t*)(b + B.order), ranges, (uint32_t*)(b + B.band), ka, va,
+                                         (uint32_t*)(b + B.order), ranges, (const uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), ka, va,
                                          gsr_variant("KEYS", 0) ? kb : nullptr, s);
             point_list = va;
         } else {
@@ -365,7 +374,7 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
             StageTimer t(GSR_STAGE_EMIT, s);
             gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
                             (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets),
-                            (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets), ka, va, nullptr, s);
+                            (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets), ka, va, s);
         }
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));  // rasterizer_impl.cu:300-308
         int in_b;

@@ -253,28 +253,69 @@ constexpr int NB_MAX = GSR_BAND_COUNTERS;  // bands
 
 struct BandGeom { int gx, gy, T, nb, bh, tmax, cull; };  // bh = tile rows per band, tmax = bh * gx; cull: see SliceRect::listed
 
-// PART_ITEMS Gaussians per thread: the one returning global atomic per band and workgroup on the eight band counters is what this
-// kernel waits for (~2.5 ns each, device-wide, whatever the address), so fewer, larger workgroups.
+// Instance / gradient-row offsets of every Gaussian (emit_keys_kernel of preprocess.hip without the keys: point_offsets, row_offsets
+// and the two offsets kept in the splat record for the backward pass) AND the per-band id lists, in one pass over the records --
+// the two used to be separate launches that each read all of them.
+// PART_ITEMS Gaussians per thread: the workgroup's one returning global atomic per band on the band counters is slow (~2.5 ns
+// each, device-wide, whatever the address), so fewer, larger workgroups.  Each 256-Gaussian quarter of an item is one block of
+// the scanned block offsets (scan_blocks_kernel works on 256-Gaussian blocks).
 constexpr int PART_ITEMS = 4;
-__global__ void __launch_bounds__(SLICE_THREADS) band_partition_kernel(int P, BandGeom G, const float* __restrict__ splat,
+__global__ void __launch_bounds__(SLICE_THREADS) emit_partition_kernel(int P, BandGeom G, float* __restrict__ splat,
+                                                                        const uint32_t* __restrict__ tiles_touched,
+                                                                        const uint32_t* __restrict__ block_offsets,
+                                                                        uint32_t* __restrict__ point_offsets,
+                                                                        const uint32_t* __restrict__ row_block_offsets,
+                                                                        uint32_t* __restrict__ row_offsets,
                                                                         uint32_t* __restrict__ band_count, uint32_t* __restrict__ band_list)
 {
     __shared__ uint32_t cnt[NB_MAX], base[NB_MAX];
+    __shared__ uint32_t wtot[PART_ITEMS][16], wtot_r[PART_ITEMS][16];
     if (threadIdx.x < NB_MAX) cnt[threadIdx.x] = 0;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int b0[PART_ITEMS], b1[PART_ITEMS];
+    uint32_t n[PART_ITEMS], nr[PART_ITEMS], incl[PART_ITEMS], incl_r[PART_ITEMS];
 #pragma unroll
     for (int e = 0; e < PART_ITEMS; e++) {
         const int idx = (blockIdx.x * PART_ITEMS + e) * SLICE_THREADS + threadIdx.x;
         b0[e] = 0; b1[e] = -1;
+        n[e] = idx < P ? tiles_touched[idx] : 0u;
+        nr[e] = 0;
+        if (n[e] != 0) {  // visible with a non-empty rectangle
+            const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)idx * GSR_SPLAT_F);
+            const float4 q0 = rec[0], q2 = rec[2], q3 = rec[3];
+            nr[e] = gsr_splat_rows(__float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w), n[e]);
+            uint32_t mnx, mny, mxx, mxy;
+            gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), G.gx, G.gy, mnx, mny, mxx, mxy);
+            b0[e] = (int)mny / G.bh; b1[e] = (int)(mxy - 1) / G.bh;
+        }
+        uint32_t in = n[e], ir = nr[e];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(in, off, 64), tr = __shfl_up(ir, off, 64);
+            if (lane >= off) { in += t; ir += tr; }
+        }
+        incl[e] = in; incl_r[e] = ir;
+        if (lane == 63) { wtot[e][wave] = in; wtot_r[e][wave] = ir; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PART_ITEMS; e++) {
+        const int idx = (blockIdx.x * PART_ITEMS + e) * SLICE_THREADS + threadIdx.x;
+        for (int b = b0[e]; b <= b1[e]; b++) atomicAdd(&cnt[b], 1u);
         if (idx < P) {
-            const SliceRect r = load_rect(splat, idx, G.gx, G.gy, 0);
-            if (r.visible && r.mxy > r.mny && r.mxx > r.mnx) { b0[e] = (int)r.mny / G.bh; b1[e] = (int)(r.mxy - 1) / G.bh; }
+            const int blk = idx >> 8;
+            uint32_t bs = block_offsets[blk], bs_r = row_block_offsets[blk];
+            for (int w = wave & ~3; w < wave; w++) { bs += wtot[e][w]; bs_r += wtot_r[e][w]; }
+            const uint32_t end = bs + incl[e], end_r = bs_r + incl_r[e];
+            point_offsets[idx] = end;
+            row_offsets[idx] = end_r;
+            if (n[e] != 0) {
+                float* rec = splat + (size_t)idx * GSR_SPLAT_F;
+                rec[SP_ROWBASE] = __uint_as_float(end_r - nr[e]);
+                rec[SP_OFFS] = __uint_as_float(end - n[e]);
+            }
         }
     }
-#pragma unroll
-    for (int e = 0; e < PART_ITEMS; e++)
-        for (int b = b0[e]; b <= b1[e]; b++) atomicAdd(&cnt[b], 1u);
     __syncthreads();
     if ((int)threadIdx.x < G.nb) {
         const uint32_t c = cnt[threadIdx.x];
@@ -884,22 +925,34 @@ size_t gsr_band_table_bytes(int W, int H)
 size_t gsr_band_list_bytes(int P, int W, int H)
 {
     const BandGeom G = band_geom((W + GSR_TILE_X - 1) / GSR_TILE_X, (H + GSR_TILE_Y - 1) / GSR_TILE_Y);
-    return (size_t)G.nb * (size_t)(P > 0 ? P : 1) * 4 + GSR_BAND_COUNTERS * 4;  // id lists + the band counters in front
+    return (size_t)G.nb * (size_t)(P > 0 ? P : 1) * 4 + GSR_BAND_COUNTERS * 4;  // id lists (+ 64 unused words in front)
 }
 
-void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* band_mem,
-                                  hipStream_t s)
+bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
+                               uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* band_count,
+                               uint32_t* band_mem, hipStream_t s)
+{
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    int nb_, bh_;
+    if (!band_mem || !gsr_band_geometry(gx, gy, &nb_, &bh_)) return false;
+    const BandGeom G = band_geom(gx, gy);
+    // the band counters were zeroed by scan_blocks_kernel (preprocess.hip)
+    hipLaunchKernelGGL(emit_partition_kernel, dim3((P + SLICE_THREADS * PART_ITEMS - 1) / (SLICE_THREADS * PART_ITEMS)), dim3(SLICE_THREADS), 0, s, P,
+                       G, splat, tiles_touched, block_offsets, point_offsets, row_block_offsets, row_offsets, band_count,
+                       band_mem + GSR_BAND_COUNTERS);
+    return true;
+}
+
+// after gsr_launch_emit_partition (banded) or gsr_launch_emit (whole-image slices)
+void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, const uint32_t* band_count,
+                                  uint32_t* band_mem, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int T = gx * gy;
     const BandGeom G = band_geom(gx, gy);
     int nb_, bh_;
     if (band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_)) {
-        // the band counters were zeroed by emit_keys_kernel (preprocess.hip), which runs right before this stage
-        uint32_t* band_count = band_mem;
-        uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
-        hipLaunchKernelGGL(band_partition_kernel, dim3((P + SLICE_THREADS * PART_ITEMS - 1) / (SLICE_THREADS * PART_ITEMS)), dim3(SLICE_THREADS), 0, s, P, G, splat,
-                           band_count, band_list);
+        const uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
         hipLaunchKernelGGL(tile_count_banded_kernel, dim3(G.nb * BAND_SLICES), dim3(SLICE_THREADS), (size_t)G.tmax * 4, s, P, G, splat,
                            band_count, band_list, table);
         hipLaunchKernelGGL(tile_colscan_banded_kernel, dim3((G.tmax + 31) / 32, G.nb), dim3(256), 0, s, G, table, totals);
@@ -913,15 +966,14 @@ void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint3
 }
 
 void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
-                                  uint32_t* ranges, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
-                                  hipStream_t s)
+                                  uint32_t* ranges, const uint32_t* band_count, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list,
+                                  uint64_t* keys_sorted, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int T = gx * gy;
     const BandGeom G = band_geom(gx, gy);
     int nb_, bh_;
     if (band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_)) {
-        const uint32_t* band_count = band_mem;
         const uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
         hipLaunchKernelGGL(tile_scatter_banded_kernel, dim3(G.nb * BAND_SLICES), dim3(SLICE_THREADS), (size_t)G.tmax * 4, s, P, G, splat,
                            band_count, band_list, table, totals, ranges, order, reinterpret_cast<uint2*>(bins));

@@ -30,12 +30,13 @@ enum GradRowField { GR_MX = 0, GR_MY = 1, GR_CX = 2, GR_CY = 3, GR_CW = 4, GR_OP
 
 struct GeomLayout {
     size_t splat, cov3D, clamped, tiles_touched, point_offsets, block_sums, block_offsets, total, radii,
-        row_offsets /* inclusive prefix of the Gaussians' gradient-row counts */, row_block_sums, row_block_offsets, bytes;
+        row_offsets /* inclusive prefix of the Gaussians' gradient-row counts */, row_block_sums, row_block_offsets,
+        band_count /* ids per band of the banded tile binning: zeroed by the scan kernel, filled by emit_partition_kernel */, bytes;
 };
 struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
 };
-#define GSR_BAND_COUNTERS 64  // band_mem = [64 counters][nb * P ids]
+#define GSR_BAND_COUNTERS 64  // most bands; band_mem = [64 unused words][nb * P ids]
 // order[] = [T tile ids by descending list length][64 + 64 counts, one per band, of the tiles whose lists a workgroup sorts
 // ("long") and of those only the 1024-thread kernel can sort ("mid")][T + T tile ids: those tiles, the segment of a band at
 // its first tile id] (binning.hip)
@@ -74,6 +75,7 @@ static inline GeomLayout gsr_geom_layout(int P)
     L.row_offsets = o; o = gsr_align(o + p * 4);
     L.row_block_sums = o; o = gsr_align(o + nb * 4);
     L.row_block_offsets = o; o = gsr_align(o + nb * 4 + 16);  // + the total
+    L.band_count = o; o = gsr_align(o + GSR_BAND_COUNTERS * 4);
     L.bytes = o;
     return L;
 }
@@ -166,11 +168,17 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
                             unsigned long long* mailbox, uint32_t seq, hipStream_t s);
 // the same with a second, independent array scanned in the same launch (in2 may be NULL); total2 = out2 + nblocks
+// zero64 (may be NULL): 64 words the kernel zeroes (the band counters of the tile binning, filled by the next stage)
 void gsr_launch_scan_blocks2(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, const uint32_t* in2,
-                             uint32_t* out2, unsigned long long* mailbox, uint32_t seq, hipStream_t s);
+                             uint32_t* out2, unsigned long long* mailbox, uint32_t seq, uint32_t* zero64, hipStream_t s);
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
                      uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint64_t* keys, uint32_t* vals,
-                     uint32_t* band_mem, hipStream_t s);
+                     hipStream_t s);
+// banded tile binning: the instance / gradient-row offsets of gsr_launch_emit (no keys) and the per-band id lists in one pass
+// over the splat records; false (nothing launched) when the banded binning does not apply to this tile grid
+bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
+                               uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* band_count,
+                               uint32_t* band_mem, hipStream_t s);
 // true (and the band count / height in tile rows) when the banded tile binning applies to this tile grid
 bool gsr_band_geometry(int gx, int gy, int* nb, int* bh);
 // returns 0 if the sorted pairs end in (ka,va), 1 if in (kb,vb)
@@ -179,11 +187,12 @@ int gsr_launch_radix_sort(uint64_t* ka, uint64_t* kb, uint32_t* va, uint32_t* vb
 static inline int gsr_sort_result_in_b(int end_bit) { return (((end_bit + 7) / 8) & 1); }
 // head: everything that does not need the R-sized arrays (band partition, tile histograms, column scan -> totals);
 // tail: scatter into the tile segments + per-tile sorts
-void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* band_mem,
-                                  hipStream_t s);
+// band_count: the band counters in the geometry buffer (GeomLayout::band_count); band_mem: the per-band id lists
+void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, const uint32_t* band_count,
+                                  uint32_t* band_mem, hipStream_t s);
 void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
-                                  uint32_t* ranges, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list, uint64_t* keys_sorted,
-                                  hipStream_t s);
+                                  uint32_t* ranges, const uint32_t* band_count, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list,
+                                  uint64_t* keys_sorted, hipStream_t s);
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 // blist / bcount / bmask: per-block lists for the skewed backward (NULL: not wanted)
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,

@@ -240,11 +240,13 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
 // host can pick it up by polling instead of queueing a copy and synchronising the stream.
 __global__ void __launch_bounds__(1024) scan_blocks_kernel(int n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                             uint32_t* __restrict__ total, const uint32_t* __restrict__ in2,
-                                                            uint32_t* __restrict__ out2, unsigned long long* mailbox, uint32_t seq)
+                                                            uint32_t* __restrict__ out2, unsigned long long* mailbox, uint32_t seq,
+                                                            uint32_t* __restrict__ zero64)
 {
     __shared__ uint32_t wtot[16], wtot2[16];
     __shared__ uint32_t carry_s, carry2_s;
     if (threadIdx.x == 0) { carry_s = 0; carry2_s = 0; }
+    if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0;  // counters the next stage fills with atomics (a memset launch would cost more)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = 0; base < n; base += 1024) {
@@ -282,19 +284,16 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(int n, const uint32_t
 // each Gaussian its first instance slot; keys are (tile id << 32) | depth bits, values the Gaussian index
 // (rasterizer_impl.cu:70-111).  Also records the inclusive offsets (point_offsets) and the exclusive
 // offset inside the splat record (used by the backward pass to address per-instance gradient rows).
-// With band_count != nullptr workgroup 0 also zeroes the band counters of the banded tile binning (binning.hip), which the
-// next kernel fills with atomics -- a memset launch between the two would cost more than this store.
+// (The banded tile binning does this inside its partition pass: emit_partition_kernel, binning.hip.)
 __global__ void __launch_bounds__(256) emit_keys_kernel(int P, int gx, int gy, float* __restrict__ splat,
                                                         const uint32_t* __restrict__ tiles_touched,
                                                         const uint32_t* __restrict__ block_offsets,
                                                         uint32_t* __restrict__ point_offsets,
                                                         const uint32_t* __restrict__ row_block_offsets, uint32_t* __restrict__ row_offsets,
-                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ band_count)
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (band_count && blockIdx.x == 0 && threadIdx.x < GSR_BAND_COUNTERS) band_count[threadIdx.x] = 0;
     const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
     // gradient rows of this Gaussian (fourth quarter of its record, written by the preprocess kernel)
     uint32_t nr = 0;
@@ -386,24 +385,23 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
                             unsigned long long* mailbox, uint32_t seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total, nullptr, nullptr, mailbox, seq);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total, nullptr, nullptr, mailbox, seq,
+                       (uint32_t*)nullptr);
 }
 
 void gsr_launch_scan_blocks2(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, const uint32_t* in2,
-                             uint32_t* out2, unsigned long long* mailbox, uint32_t seq, hipStream_t s)
+                             uint32_t* out2, unsigned long long* mailbox, uint32_t seq, uint32_t* zero64, hipStream_t s)
 {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total, in2, out2, mailbox, seq);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offsets, total, in2, out2, mailbox, seq, zero64);
 }
 
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
                      uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint64_t* keys, uint32_t* vals,
-                     uint32_t* band_mem, hipStream_t s)
+                     hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-    int nb = 0, bh = 1;
-    uint32_t* band_count = (band_mem && gsr_band_geometry(gx, gy, &nb, &bh)) ? band_mem : nullptr;
     hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, splat, tiles_touched, block_offsets,
-                       point_offsets, row_block_offsets, row_offsets, keys, vals, band_count);
+                       point_offsets, row_block_offsets, row_offsets, keys, vals);
 }
 
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s)

@@ -424,6 +424,20 @@ def test_random_configuration_sweep(seed):
     assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
 
 
+def test_binning_buffer_regrown_after_the_early_head():
+    """The wrapper sizes the binning buffer from the last num_rendered seen for (P, W, H); when a frame needs more, gsr_forward has
+    already run the R-independent head of the binning on the small buffer and returns 1, and the frame is finished by
+    gsr_forward_render -- which runs that head a second time on the same geometry (the band counters must start from zero again)."""
+    P, W, H = 6000, 200, 150
+    for lo, hi in ((0.002, 0.004), (0.05, 0.3)):  # few instances first, then many times more
+        g, cam = scene(P, W, H, 150.0, seed=3, scale_lo=lo, scale_hi=hi)
+        st = oracle_forward(g, cam)
+        ctx = hip_forward_raw(g, cam)
+        assert_forward_bit_exact(ctx, st)
+        dL = np.random.default_rng(5).standard_normal((3, H, W)).astype(np.float32)
+        assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+
+
 def test_thin_diagonal_splats_reach_mask():
     """Needle-shaped Gaussians at every orientation, opacities from just above 1/255 to 1: the per-tile-row reach mask
     (common.h, gsr_reach_mask) decides which instances are listed and which own a gradient row; a tile it wrongly left out
