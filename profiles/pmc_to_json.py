@@ -16,7 +16,7 @@ import sys
 STAGE = {
     "preprocess_kernel": "preprocess", "scan_blocks_kernel": "scan", "emit_keys_kernel": "emit_keys",
     "tile_count_kernel": "radix_sort", "tile_colscan_kernel": "radix_sort", "tile_starts_kernel": "radix_sort",
-    "band_partition_kernel": "radix_sort", "tile_count_banded_kernel": "radix_sort", "tile_colscan_banded_kernel": "radix_sort",
+    "emit_partition_kernel": "emit_keys", "band_partition_kernel": "radix_sort", "tile_count_banded_kernel": "radix_sort", "tile_colscan_banded_kernel": "radix_sort",
     "tile_scatter_banded_kernel": "radix_sort", "tile_sort_mid_kernel": "radix_sort",
     "tile_scatter_kernel": "radix_sort", "tile_sort_small_kernel": "radix_sort", "tile_sort_large_kernel": "radix_sort", "global_hist_kernel": "radix_sort",
     "block_hist_kernel": "radix_sort", "bin_scan_kernel": "radix_sort", "scatter_kernel": "radix_sort",
