@@ -49,7 +49,7 @@ struct GaussBackwardPtrs {
 // 16-byte loads at the start of its chain and stores its dL/dSH row the same way -- no SH tile in LDS, so the workgroup's LDS is
 // the small gradient-row buffer alone and twice as many waves are in flight (the kernel is latency-bound: with half the waves
 // it takes 1.5x as long).  Culled Gaussians read no SH at all.
-template <bool RAW, int BS, bool DIRECT>
+template <bool RAW, int BS, bool DIRECT, int RK = 1>
 __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
 {
     extern __shared__ float s_tile[];  // [BS][3M + 1]
@@ -59,6 +59,21 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     const size_t tile_base = (size_t)blockIdx.x * BS * n3;
     const bool valid = idx < a.P;
     const bool visible = valid && a.radii[idx] > 0;
+
+    // the Gaussian's own parameters: requested here so that they arrive while the gradient rows are summed (the chain below would
+    // otherwise start with one more exposed round trip per workgroup)
+    float mx = 0.f, my = 0.f, mz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc_in[3] = {0.f, 0.f, 0.f};
+    if (visible) {
+        mx = a.means3D[3 * idx]; my = a.means3D[3 * idx + 1]; mz = a.means3D[3 * idx + 2];
+        const float* cov3D = a.cov3D_in + 6 * (size_t)idx;
+        c0 = cov3D[0]; c1 = cov3D[1]; c2 = cov3D[2]; c3 = cov3D[3]; c4 = cov3D[4]; c5 = cov3D[5];
+        if (a.has_scales) {
+            q_in = reinterpret_cast<const float4*>(a.rotations)[idx];
+            sc_in[0] = a.scales[3 * idx]; sc_in[1] = a.scales[3 * idx + 1]; sc_in[2] = a.scales[3 * idx + 2];
+        }
+    }
 
     // ---- sum each Gaussian's gradient rows ----
     // The rows of this workgroup's Gaussians are one contiguous range of grad_rows (emission order).  They are streamed
@@ -91,13 +106,34 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
                 my_n = gsr_splat_rows(__float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w), a.tiles_touched[idx]);
             }
         }
-        const uint32_t CH = (uint32_t)a.lds_floats / GSR_GROW_F;  // rows per chunk
+        const uint32_t CH = DIRECT ? (uint32_t)(RK * BS) : (uint32_t)a.lds_floats / GSR_GROW_F;  // rows per chunk
         float4* s_rows = reinterpret_cast<float4*>(s_tile);
         const float4* g4 = reinterpret_cast<const float4*>(a.grad_rows);
+        // DIRECT: chunks of RK*BS rows = 3*RK float4 per thread, the next chunk requested into registers before this one is summed
+        constexpr int NPRE = 3 * RK;
+        float4 pre[DIRECT ? NPRE : 1];
+        auto request = [&](uint32_t cb) {
+            const uint32_t n3r = min(CH, end - cb) * 3;
+#pragma unroll
+            for (int t = 0; t < NPRE; t++) {
+                const uint32_t f = threadIdx.x + t * BS;
+                pre[DIRECT ? t : 0] = f < n3r ? g4[(size_t)cb * 3 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        if (DIRECT && begin < end) request(begin);
         for (uint32_t cb = begin; cb < end; cb += CH) {
             const uint32_t nrows = min(CH, end - cb);
-            for (uint32_t f = threadIdx.x; f < nrows * 3; f += BS) s_rows[f] = g4[(size_t)cb * 3 + f];
+            if (DIRECT) {
+#pragma unroll
+                for (int t = 0; t < NPRE; t++) {
+                    const uint32_t f = threadIdx.x + t * BS;
+                    if (f < nrows * 3) s_rows[f] = pre[DIRECT ? t : 0];
+                }
+            } else {
+                for (uint32_t f = threadIdx.x; f < nrows * 3; f += BS) s_rows[f] = g4[(size_t)cb * 3 + f];
+            }
             __syncthreads();
+            if (DIRECT && cb + CH < end) request(cb + CH);
             const uint32_t lo = max(my_off, cb), hi = min(my_off + my_n, cb + nrows);
             for (uint32_t r = lo; r < hi; r++) {
                 const float4 r0 = s_rows[(r - cb) * 3], r1 = s_rows[(r - cb) * 3 + 1], r2 = s_rows[(r - cb) * 3 + 2];
@@ -156,11 +192,8 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
 
     const float* v = a.viewmatrix;
     const float* proj = a.projmatrix;
-    const float mx = a.means3D[3 * idx], my = a.means3D[3 * idx + 1], mz = a.means3D[3 * idx + 2];
 
     // ---- computeCov2DCUDA (backward.cu:144-274) ----
-    const float* cov3D = a.cov3D_in + 6 * (size_t)idx;
-    const float c0 = cov3D[0], c1 = cov3D[1], c2 = cov3D[2], c3 = cov3D[3], c4 = cov3D[4], c5 = cov3D[5];
     float tx = v[0] * mx + v[4] * my + v[8] * mz + v[12];
     float ty = v[1] * mx + v[5] * my + v[9] * mz + v[13];
     const float tz_ = v[2] * mx + v[6] * my + v[10] * mz + v[14];
@@ -346,8 +379,8 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
 
     if (a.has_scales) {
         // computeCov3D backward (backward.cu:278-341)
-        float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
-        float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+        float4 q = q_in;
+        float sc[3] = {sc_in[0], sc_in[1], sc_in[2]};
         float qn = 1.0f;
         if (RAW) {
             sc[0] = gsr_expf(sc[0]); sc[1] = gsr_expf(sc[1]); sc[2] = gsr_expf(sc[2]);
@@ -456,8 +489,10 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     const int bs = gsr_variant("GB_BLOCK", 128);
     const bool direct = !a.raw && a.has_shs && a.M == 16 && gsr_variant("GB_DIRECT", 1);
-    // LDS: the SH tile, or room for 4 (2 without the tile) gradient rows per Gaussian and chunk
-    size_t lds = direct ? (size_t)2 * bs * GSR_GROW_F * 4 : (size_t)bs * (3 * a.M + 1) * 4;
+    // LDS: the SH tile and room for 4 gradient rows per Gaussian and chunk, or (DIRECT) the row chunk / the dL/dSH pieces alone
+    // DIRECT: chunks of one gradient row per thread (measured: 82 us; two or four rows per thread 86 us)
+    size_t lds = direct ? (size_t)bs * GSR_GROW_F * 4 : (size_t)bs * (3 * a.M + 1) * 4;
+    if (direct && lds < (size_t)bs * 17 * 4) lds = (size_t)bs * 17 * 4;  // the dL/dSH pieces
     if (!direct && lds < (size_t)4 * bs * GSR_GROW_F * 4) lds = (size_t)4 * bs * GSR_GROW_F * 4;
     p.lds_floats = (int)(lds / 4);
     lds += (size_t)gsr_variant("LDS_PAD", 0);
