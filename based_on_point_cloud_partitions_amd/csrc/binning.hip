@@ -256,10 +256,10 @@ struct BandGeom { int gx, gy, T, nb, bh, tmax, cull; };  // bh = tile rows per b
 // Instance / gradient-row offsets of every Gaussian (emit_keys_kernel of preprocess.hip without the keys: point_offsets, row_offsets
 // and the two offsets kept in the splat record for the backward pass) AND the per-band id lists, in one pass over the records --
 // the two used to be separate launches that each read all of them.
-// PART_ITEMS Gaussians per thread: the workgroup's one returning global atomic per band on the band counters is slow (~2.5 ns
-// each, device-wide, whatever the address), so fewer, larger workgroups.  Each 256-Gaussian quarter of an item is one block of
-// the scanned block offsets (scan_blocks_kernel works on 256-Gaussian blocks).
-constexpr int PART_ITEMS = 4;
+// PART_ITEMS Gaussians per thread (measured on 500k Gaussians: 1 -> 15.7 us, 2 -> 16.0 us, 4 -> 17.6 us; the workgroup's returning
+// global atomics on the band counters favour few workgroups, filling 256 CUs many).  Each 256-Gaussian quarter of an item is one
+// block of the scanned block offsets (scan_blocks_kernel works on 256-Gaussian blocks).
+constexpr int PART_ITEMS = 2;
 __global__ void __launch_bounds__(SLICE_THREADS) emit_partition_kernel(int P, BandGeom G, float* __restrict__ splat,
                                                                         const uint32_t* __restrict__ tiles_touched,
                                                                         const uint32_t* __restrict__ block_offsets,
