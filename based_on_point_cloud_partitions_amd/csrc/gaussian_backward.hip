@@ -490,8 +490,9 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     const int bs = gsr_variant("GB_BLOCK", 128);
     const bool direct = !a.raw && a.has_shs && a.M == 16 && gsr_variant("GB_DIRECT", 1);
     // LDS: the SH tile and room for 4 gradient rows per Gaussian and chunk, or (DIRECT) the row chunk / the dL/dSH pieces alone
-    // DIRECT: chunks of one gradient row per thread (measured: 82 us; two or four rows per thread 86 us)
-    size_t lds = direct ? (size_t)bs * GSR_GROW_F * 4 : (size_t)bs * (3 * a.M + 1) * 4;
+    // DIRECT: chunks of GB_RK gradient rows per thread (500k Gaussians: 1 -> 82 us, 2 or 4 -> 86 us)
+    const int rk = gsr_variant("GB_RK", 1) == 2 ? 2 : 1;
+    size_t lds = direct ? (size_t)rk * bs * GSR_GROW_F * 4 : (size_t)bs * (3 * a.M + 1) * 4;
     if (direct && lds < (size_t)bs * 17 * 4) lds = (size_t)bs * 17 * 4;  // the dL/dSH pieces
     if (!direct && lds < (size_t)4 * bs * GSR_GROW_F * 4) lds = (size_t)4 * bs * GSR_GROW_F * 4;
     p.lds_floats = (int)(lds / 4);
@@ -499,10 +500,12 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     const dim3 grid((a.P + bs - 1) / bs), block(bs);
     if (bs == 256) {
         if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256, false>), grid, block, lds, s, p, h_x, h_y);
+        else if (direct && rk == 2) hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, true, 2>), grid, block, lds, s, p, h_x, h_y);
         else if (direct) hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, true>), grid, block, lds, s, p, h_x, h_y);
         else hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, false>), grid, block, lds, s, p, h_x, h_y);
     } else {
         if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128, false>), grid, block, lds, s, p, h_x, h_y);
+        else if (direct && rk == 2) hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, true, 2>), grid, block, lds, s, p, h_x, h_y);
         else if (direct) hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, true>), grid, block, lds, s, p, h_x, h_y);
         else hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, false>), grid, block, lds, s, p, h_x, h_y);
     }
