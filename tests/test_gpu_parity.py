@@ -147,6 +147,26 @@ def test_many_equal_depths_tie_break_by_index():
     assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
 
 
+@pytest.mark.parametrize("distinct,rep,size,lo_len,hi_len", [(40, 20, 64, 17, 511), (120, 24, 96, 512, 2048)])
+def test_equal_depths_overflow_in_short_and_long_lists(distinct, rep, size, lo_len, hi_len):
+    """More than 16 exact depth ties in one tile list overflow a depth bucket of the per-tile sort, which then falls back to the
+    bitonic network: once in a list a single wave sorts (fewer than 512 entries), once in one a 256-thread workgroup sorts."""
+    import torch
+
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    g, cam = scene(distinct, size, size, 60.0, seed=29, scale_lo=0.05, scale_hi=0.2)
+    idx = torch.randperm(distinct * rep, generator=torch.Generator().manual_seed(2)) % distinct
+    g2 = syn.SyntheticGaussians(g.xyz[idx], g.scales[idx], g.rotations[idx], g.opacities[idx] * 0.1, g.shs[idx])
+    st = oracle_forward(g2, cam)
+    ln = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert ((ln >= lo_len) & (ln <= hi_len)).any(), ln.max()
+    ctx = hip_forward_raw(g2, cam)
+    assert_forward_bit_exact(ctx, st)
+    dL = np.random.default_rng(3).standard_normal((3, size, size)).astype(np.float32)
+    assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+
+
 def test_equal_depths_in_mid_length_lists_overflow_to_the_network():
     # thousands of exact depth ties in lists of 2049..8192 entries: the 1024-thread bucket sort overflows a bucket and
     # falls back to the bitonic network, still in LDS
