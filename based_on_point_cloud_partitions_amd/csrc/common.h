@@ -56,6 +56,11 @@ struct BinLayout {
     uint32_t sort_blocks;
 };
 
+// 4-byte-aligned vector loads (a features_rest row is 45 floats: its 16-byte pieces are only dword-aligned; gfx950 global
+// loads of 2-4 dwords need no more than that)
+typedef float gsr_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float gsr_f3u __attribute__((ext_vector_type(3), aligned(4)));
+
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static inline GeomLayout gsr_geom_layout(int P)

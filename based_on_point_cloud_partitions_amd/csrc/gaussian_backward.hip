@@ -45,7 +45,7 @@ struct GaussBackwardPtrs {
 // RAW (gsr_backward_params): scales / rotations are the pre-activation parameters; the chain rule through exp / sigmoid /
 // normalize is applied here and dL/dSH leaves LDS as the two tensors dL/dfeatures_dc, dL/dfeatures_rest -- the autograd
 // passes of scene/gaussian_model.py:102-122 (exp, sigmoid, normalize, cat backward) never touch HBM.
-// DIRECT (degree-3 storage, 16 coefficients, activated parameters): a visible Gaussian reads its 192-byte SH row with twelve
+// DIRECT (degree-3 storage, 16 coefficients; activated parameters or the raw features_dc / features_rest pair): a visible Gaussian reads its 192-byte SH row with twelve
 // 16-byte loads at the start of its chain and stores its dL/dSH row the same way -- no SH tile in LDS, so the workgroup's LDS is
 // the small gradient-row buffer alone and twice as many waves are in flight (the kernel is latency-bound: with half the waves
 // it takes 1.5x as long).  Culled Gaussians read no SH at all.
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
         const float hop = -0.5f * op;
         g[GR_CX] = hop * g[2]; g[GR_CY] = hop * g[3]; g[GR_CW] = hop * g[4];
     }
-    if (RAW) {
+    if (RAW && !DIRECT) {
         sh_cols_load(a.features_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
         if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
     } else if (!DIRECT && a.has_shs) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
@@ -273,7 +273,17 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
 
     if (DIRECT || a.has_shs) {
         // computeColorFromSH backward (backward.cu:20-139)
-        if (DIRECT) {
+        if (DIRECT && RAW) {  // 3 + 45 floats from the two raw tensors (rows of 12 and 180 bytes, dword-aligned pieces)
+            const gsr_f3u d = *reinterpret_cast<const gsr_f3u*>(a.features_dc + (size_t)idx * 3);
+            shr[0] = d.x; shr[1] = d.y; shr[2] = d.z;
+            const float* row_in = a.features_rest + (size_t)idx * 45;
+#pragma unroll
+            for (int q = 0; q < 11; q++) {
+                const gsr_f4u t = *reinterpret_cast<const gsr_f4u*>(row_in + 4 * q);
+                shr[3 + 4 * q] = t.x; shr[4 + 4 * q] = t.y; shr[5 + 4 * q] = t.z; shr[6 + 4 * q] = t.w;
+            }
+            shr[DIRECT ? 47 : 0] = row_in[44];
+        } else if (DIRECT) {
             const float4* row_in = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
 #pragma unroll
             for (int q = 0; q < 12; q++) {
@@ -448,16 +458,27 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     if (DIRECT) {
         // the dL/dSH rows in three pieces of 16 floats: products into an LDS tile of [BS][17] (the gradient-row buffer is free by
         // now), out with coalesced 16-byte stores (64 contiguous bytes per row and piece)
-        float* g_out = a.dL_dsh + tile_base;
+        float* g_out = RAW ? nullptr : a.dL_dsh + tile_base;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
 #pragma unroll
             for (int k = 0; k < 16; k++) s_tile[threadIdx.x * 17 + k] = w[(16 * c + k) / 3] * dRGBo[(16 * c + k) % 3];
             __syncthreads();
-            for (int f = threadIdx.x; f < rows * 4; f += BS) {
-                const int r = f >> 2, q = f & 3;
-                const float* sp = s_tile + r * 17 + 4 * q;
-                *reinterpret_cast<float4*>(g_out + (size_t)r * 48 + 16 * c + 4 * q) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            if (RAW) {  // the row splits into dL/dfeatures_dc (floats 0..2) and dL/dfeatures_rest (3..47): coalesced dword stores
+                float* o_dc = a.dL_dfeatures_dc + (size_t)blockIdx.x * BS * 3;
+                float* o_rest = a.dL_dfeatures_rest + (size_t)blockIdx.x * BS * 45;
+                for (int f = threadIdx.x; f < rows * 16; f += BS) {
+                    const int r = f >> 4, j = 16 * c + (f & 15);
+                    const float v = s_tile[r * 17 + (f & 15)];
+                    if (j < 3) o_dc[r * 3 + j] = v;
+                    else o_rest[r * 45 + j - 3] = v;
+                }
+            } else {
+                for (int f = threadIdx.x; f < rows * 4; f += BS) {
+                    const int r = f >> 2, q = f & 3;
+                    const float* sp = s_tile + r * 17 + 4 * q;
+                    *reinterpret_cast<float4*>(g_out + (size_t)r * 48 + 16 * c + 4 * q) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                }
             }
             __syncthreads();
         }
@@ -488,7 +509,7 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.P = a.P; p.D = a.D; p.M = a.M; p.has_shs = a.has_shs; p.has_scales = a.has_scales;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     const int bs = gsr_variant("GB_BLOCK", 128);
-    const bool direct = !a.raw && a.has_shs && a.M == 16 && gsr_variant("GB_DIRECT", 1);
+    const bool direct = (a.raw ? (a.features_rest != nullptr && a.dL_dfeatures_rest != nullptr) : a.has_shs != 0) && a.M == 16 && gsr_variant("GB_DIRECT", 1);
     // LDS: the SH tile and room for 4 gradient rows per Gaussian and chunk, or (DIRECT) the row chunk / the dL/dSH pieces alone
     // DIRECT: chunks of GB_RK gradient rows per thread (500k Gaussians: 1 -> 82 us, 2 or 4 -> 86 us)
     const int rk = gsr_variant("GB_RK", 1) == 2 ? 2 : 1;
@@ -499,12 +520,14 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     lds += (size_t)gsr_variant("LDS_PAD", 0);
     const dim3 grid((a.P + bs - 1) / bs), block(bs);
     if (bs == 256) {
-        if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256, false>), grid, block, lds, s, p, h_x, h_y);
+        if (a.raw && direct) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256, true>), grid, block, lds, s, p, h_x, h_y);
+        else if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256, false>), grid, block, lds, s, p, h_x, h_y);
         else if (direct && rk == 2) hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, true, 2>), grid, block, lds, s, p, h_x, h_y);
         else if (direct) hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, true>), grid, block, lds, s, p, h_x, h_y);
         else hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, false>), grid, block, lds, s, p, h_x, h_y);
     } else {
-        if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128, false>), grid, block, lds, s, p, h_x, h_y);
+        if (a.raw && direct) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128, true>), grid, block, lds, s, p, h_x, h_y);
+        else if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128, false>), grid, block, lds, s, p, h_x, h_y);
         else if (direct && rk == 2) hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, true, 2>), grid, block, lds, s, p, h_x, h_y);
         else if (direct) hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, true>), grid, block, lds, s, p, h_x, h_y);
         else hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, false>), grid, block, lds, s, p, h_x, h_y);

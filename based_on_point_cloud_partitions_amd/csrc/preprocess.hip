@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
     extern __shared__ float s_sh[];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n3 = 3 * a.M, sh_stride = n3 + 1;
-    if (RAW) {
+    if (RAW && !a.sh_direct) {
         const int rows = min(256, a.P - (int)blockIdx.x * 256);
         sh_cols_load(a.features_dc + (size_t)blockIdx.x * 256 * 3, s_sh, rows, 3, sh_stride, 0);
         if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * 256 * (n3 - 3), s_sh, rows, n3 - 3, sh_stride, 3);
@@ -181,7 +181,20 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
                         F3 dir{dx / len, dy / len, dz / len};
                         bool cl[3];
                         F3 c;
-                        if (!RAW && a.sh_direct) {
+                        if (RAW && a.sh_direct) {
+                            // the same from the two raw tensors: 3 + 45 floats (rows of 12 and 180 bytes, dword-aligned pieces)
+                            float sh[48];
+                            const gsr_f3u d = *reinterpret_cast<const gsr_f3u*>(a.features_dc + (size_t)idx * 3);
+                            sh[0] = d.x; sh[1] = d.y; sh[2] = d.z;
+                            const float* row = a.features_rest + (size_t)idx * 45;
+#pragma unroll
+                            for (int q = 0; q < 11; q++) {
+                                const gsr_f4u v = *reinterpret_cast<const gsr_f4u*>(row + 4 * q);
+                                sh[3 + 4 * q] = v.x; sh[4 + 4 * q] = v.y; sh[5 + 4 * q] = v.z; sh[6 + 4 * q] = v.w;
+                            }
+                            sh[47] = row[44];
+                            c = sh_to_rgb(3, sh, dir, cl);
+                        } else if (!RAW && a.sh_direct) {
                             // degree 3, 16 coefficients: the visible Gaussian reads its own 192-byte row with twelve 16-byte loads (no
                             // LDS tile, so nothing but registers limits the waves in flight; culled Gaussians read nothing)
                             float sh[48];
@@ -374,8 +387,8 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     p.radii = a.radii; p.splat = a.splat; p.cov3D = a.cov3D; p.clamped = a.clamped; p.tiles_touched = a.tiles_touched;
     p.block_sums = a.block_sums; p.row_block_sums = a.row_block_sums; p.features_dc = a.features_dc; p.features_rest = a.features_rest;
-    p.sh_direct = (!a.raw && a.shs && a.M == 16 && a.D == 3 && gsr_variant("PRE_DIRECT", 1)) ? 1 : 0;
-    const size_t lds = (((a.shs && !p.sh_direct) || a.raw) ? (size_t)256 * (3 * a.M + 1) * 4 : 0) + (size_t)gsr_variant("LDS_PAD", 0);
+    p.sh_direct = ((a.raw ? a.features_rest != nullptr : a.shs != nullptr) && a.M == 16 && a.D == 3 && gsr_variant("PRE_DIRECT", 1)) ? 1 : 0;
+    const size_t lds = (((a.shs || a.raw) && !p.sh_direct) ? (size_t)256 * (3 * a.M + 1) * 4 : 0) + (size_t)gsr_variant("LDS_PAD", 0);
     if (a.raw)
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, s, p, focal_x, focal_y, gx, gy);
     else
