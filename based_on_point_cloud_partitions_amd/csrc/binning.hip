@@ -7,12 +7,15 @@
 //   1. tile_count:   each workgroup takes a slice of the Gaussians and histograms the tiles of their rectangles in LDS
 //                    (one LDS atomic per instance), then stores its row of the [workgroup][tile] table;
 //   2. tile_colscan: per tile, exclusive prefix over the workgroups (in place) + the tile's total;
-//   3. tile_scatter: same slicing as (1); every workgroup scans the totals into tile starts (workgroup 0 stores them as the
-//                    reference's `ranges`), then an LDS cursor per tile hands out slots and the (depth bits, id) pairs go
-//                    straight into their tile's segment (8 B/instance, written once);
-//   4. tile_sort:    one workgroup per tile sorts its segment by (depth, id) in LDS -- bucket sort + insertion sort for
-//                    lists up to 1024 entries, a normalized bitonic network (all comparators ascending, tail padded
-//                    virtually) for longer ones -- and writes point_list (+ keys).
+//   3. tile_scatter: same slicing as (1); every workgroup derives the tile starts from the totals (the first slice stores them
+//                    as the reference's `ranges`), then an LDS cursor per tile hands out slots and the (depth bits, id) pairs
+//                    go straight into their tile's segment (8 B/instance, written once);
+//   4. tile_sort:    every tile's segment is sorted by (depth, id) in LDS -- a bucket sort whose entries rank themselves inside
+//                    their depth bucket; ONE wave per list of fewer than 512 entries, a 256-thread workgroup up to 2048, a
+//                    1024-thread workgroup up to 8192, a normalized bitonic network (all comparators ascending, tail padded
+//                    virtually) beyond that and when a bucket overflows -- and written out as point_list (+ keys); the same
+//                    launch orders the tiles by list length for the blend kernels.
+// The default path runs (1)-(3) per band of tile rows (see "Banded variant" below), fed by emit_partition_kernel.
 // The order in which (4) fills a segment is arbitrary (LDS atomics), but ids are unique within a tile, so the sorted
 // result is unique: ascending depth bits, ties by ascending id = the stable sort's emission order.
 // Integer/byte work, HBM + LDS bound; no MFMA.
@@ -244,7 +247,7 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int 
 // Banded variant of (1)-(3).  With slices that cover the whole image, a slice contributes only ~7 entries to any one tile:
 // the scatter then writes 8-byte pairs into ~60-byte runs spread over all tile segments, every store a partial line
 // (measured: 244 MB of write traffic for 30 MB of pairs).  Here the tile rows are cut into NB horizontal bands and the
-// visible Gaussians are first partitioned into per-band id lists (band_partition_kernel; a Gaussian whose rectangle crosses
+// visible Gaussians are first partitioned into per-band id lists (emit_partition_kernel; a Gaussian whose rectangle crosses
 // a band boundary is listed in each band it touches).  A slice then works on ONE band: its runs per tile are NB times longer, the
 // [slice][tile] table shrinks NB-fold (band tiles only), and the LDS histograms cover a band instead of the image.
 // ---------------------------------------------------------------------------------------------------------------------
