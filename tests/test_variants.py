@@ -10,7 +10,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = dict(QUAD=1, CULL=1, BIN=2, LPT=1, MAILBOX=1, BWD_RS=1, BWD_FASTEXP=1, BWD_BATCH=128, KEYS=0, WAVE8X8=1, EARLY=1, BANDS=8,
-                GB_BLOCK=128, BLK=0)
+                GB_BLOCK=128, BLK=0, PRE_DIRECT=1, GB_DIRECT=1, GB_RK=1)
 ALTERNATIVES = [
     dict(QUAD=0),                 # every wave walks the whole tile list
     dict(QUAD=0, CULL=0),         # ... over the reference's lists
@@ -26,6 +26,10 @@ ALTERNATIVES = [
     dict(WAVE8X8=0),              # 16x4 pixel strips per wave
     dict(BANDS=16),
     dict(GB_BLOCK=256),
+    dict(PRE_DIRECT=0),           # SH rows through the LDS tile in preprocess
+    dict(GB_DIRECT=0),            # ... and in the per-Gaussian backward
+    dict(GB_RK=2),                # two gradient rows per thread and chunk
+    dict(GB_BLOCK=256, GB_RK=2),
 ]
 
 
