@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 
@@ -71,8 +71,7 @@ PROTOTYPES = {
     "gsr_knn_scratch_bytes": (c_size, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),
-    "gsr_debug_export_blocks": (c_int, [c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "gsr_set_variant": (None, [ctypes.c_char_p, c_int]),
+    "gsr_set_variant": (c_int, [ctypes.c_char_p, c_int]),
     "gsr_get_variant": (c_int, [ctypes.c_char_p, c_int]),
     "gsr_profile_enable": (None, [c_int]),
     "gsr_profile_select": (None, [ctypes.c_uint32]),
@@ -137,7 +136,7 @@ def profile_collect():
 
 def set_variant(name, value):
     """Overrides the experiment switch GSR_<name> for this process (tests / A-B runs)."""
-    load().gsr_set_variant(name.encode(), int(value))
+    check(load().gsr_set_variant(name.encode(), int(value)), "gsr_set_variant")
 
 
 def get_variant(name, default):

@@ -65,14 +65,15 @@ struct StageTimer {
 // pinned memory and the host polls that word.
 constexpr int kMailSlots = 64;
 struct Mailbox { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; };
-Mailbox g_mail[16];
+constexpr int kMailDevices = 64;  // more devices than that: the forward falls back to memcpy + stream sync
+Mailbox g_mail[kMailDevices];
 std::mutex g_mail_mu;
 uint32_t g_mail_seq = 0;
 
 bool mailbox_acquire(unsigned long long** host_slot, unsigned long long** dev_slot, uint32_t* seq)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMailDevices) return false;
     std::lock_guard<std::mutex> lk(g_mail_mu);
     Mailbox& m = g_mail[dev];
     if (!m.host) {
@@ -91,15 +92,25 @@ bool mailbox_acquire(unsigned long long** host_slot, unsigned long long** dev_sl
     return true;
 }
 
-// Waits for the tagged value; falls back to a stream synchronisation if it does not show up (bounded spin).
-bool mailbox_wait(const unsigned long long* host_slot, uint32_t seq, uint32_t* value)
+// Waits for the tagged value.  Every 2^17 spins (~a millisecond) the stream is queried: if it has drained (hipSuccess) without the word
+// showing up, or reports an error (a faulted kernel), the wait ends at once and the caller falls back to memcpy + stream
+// synchronisation, which surfaces the error -- a dead kernel stalls the host for a millisecond, not for seconds.
+bool mailbox_wait(const unsigned long long* host_slot, uint32_t seq, uint32_t* value, hipStream_t s)
 {
     const volatile unsigned long long* p = host_slot;
     for (long spin = 0; spin < 400000000L; spin++) {
         const unsigned long long v = *p;
         if ((uint32_t)(v >> 32) == seq) { *value = (uint32_t)v; return true; }
         __builtin_ia32_pause();
-        if ((spin & 0xFFFFF) == 0xFFFFF && hipPeekAtLastError() != hipSuccess) return false;
+        if ((spin & 0x1FFFF) == 0x1FFFF) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipErrorNotReady) {  // drained or failed: one last look at the word, then give up
+                const unsigned long long v2 = *p;
+                if (q == hipSuccess && (uint32_t)(v2 >> 32) == seq) { *value = (uint32_t)v2; return true; }
+                if (q != hipSuccess) (void)hipGetLastError();
+                return false;
+            }
+        }
     }
     return false;
 }
@@ -159,20 +170,16 @@ int gsr_variant(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
-static void gsr_variant_store(const char* name, int value)
+static bool gsr_variant_store(const char* name, int value)
 {
     std::lock_guard<std::mutex> lk(g_variant_mu);
     for (int i = 0; i < g_n_variants; i++)
-        if (strcmp(g_variants[i].name, name) == 0) { g_variants[i].set = true; g_variants[i].value = value; return; }
+        if (strcmp(g_variants[i].name, name) == 0) { g_variants[i].set = true; g_variants[i].value = value; return true; }
+    return false;
 }
 
-// The per-block lists + Gaussian-per-lane backward need the banded/tile binning (launch order) and the 8x8 wave layout.
-// Off by default: measured on config 2 the per-block lists cost the forward 0.04 ms and the Gaussian-per-lane backward is no
-// faster than the pixel-per-lane kernel (profiles/README.md, round 2); kept as a tested alternative (GSR_BLK=1).
-bool gsr_block_lists_enabled() { return gsr_variant("BLK", 0) && gsr_variant("BIN", 1) && gsr_variant("WAVE8X8", 1); }
-
 // Tile lists without the (Gaussian, tile) instances the splat cannot reach (GSR_CULL, default on; needs the tile binning).  The
-// reference lists every tile of the square around the 3-sigma circle of the larger axis (auxiliary.h:46-56): on config 2, 58 % of
+// reference lists every tile of the square around the 3-sigma circle of the larger axis (auxiliary.h:46-56): on config 2, 40 % of
 // those instances lie outside the alpha >= 1/255 ellipse (gsr_reach_mask) and cannot contribute to any pixel.  Leaving them out
 // changes no pixel and no gradient; GSR_CULL=0 keeps the reference's lists bit for bit (sort keys, point_list, ranges, n_contrib).
 bool gsr_cull_enabled() { return gsr_variant("CULL", 1) && gsr_variant("BIN", 1); }
@@ -183,40 +190,24 @@ int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 int gsr_get_variant(const char* name, int default_value) { return name ? gsr_variant(name, default_value) : default_value; }
 
-void gsr_set_variant(const char* name, int value)
+int gsr_set_variant(const char* name, int value)
 {
-    if (!name) return;
+    if (!name) return fail(-1, "gsr_set_variant: NULL name");
     gsr_variant(name, 0);  // make sure the entry exists
-    gsr_variant_store(name, value);
+    if (!gsr_variant_store(name, value)) return fail(-1, "gsr_set_variant: switch %s cannot be stored (name too long or table full)", name);
+    return 0;
 }
 const char* gsr_last_error(void) { return g_err; }
 
 size_t gsr_geometry_bytes(int P) { return gsr_geom_layout(P).bytes; }
 size_t gsr_image_bytes(int W, int H) { return gsr_image_layout(W, H).bytes; }
 size_t gsr_binning_bytes(int64_t R, int P, int W, int H) { return gsr_bin_layout((long)R, P, W, H).bytes; }
-// Backward scratch.  Per-block lists (default): up to one 48-byte row per (instance, quadrant) pair -- only the pairs the
-// forward marked are ever written or read, the rest is address space --, the row numbering rowinfo[R + 1] and its scan
-// workspace.  Without them: one row per instance.
-struct BwdScratch { size_t rows, rowinfo, sums, offsets, total, queues, bytes; };
-static BwdScratch bwd_scratch_layout(int64_t R, int W, int H)
+// Backward scratch: one 48-byte gradient row per (Gaussian, tile) instance at most (only reachable instances own one).
+size_t gsr_backward_scratch_bytes(int64_t R, int W, int H)
 {
-    BwdScratch L;
-    const size_t r = (size_t)(R > 0 ? R : 1);
-    size_t o = 0;
-    L.rows = o;
-    if (!gsr_block_lists_enabled()) { o = gsr_align(r * GSR_GROW_F * 4); L.rowinfo = L.sums = L.offsets = L.total = L.queues = o; L.bytes = o; return L; }
-    o = gsr_align(4 * r * GSR_GROW_F * 4);
-    const size_t nb = gsr_row_scan_blocks(R);
-    L.rowinfo = o; o = gsr_align(o + (r + 1) * 4);
-    L.sums = o; o = gsr_align(o + nb * 4);
-    L.offsets = o; o = gsr_align(o + nb * 4);
-    L.total = o; o = gsr_align(o + 16);
     (void)W; (void)H;
-    L.queues = o; o = gsr_align(o + gsr_skew_queue_bytes());  // heads of the blend kernel's block queues
-    L.bytes = o;
-    return L;
+    return gsr_align((size_t)(R > 0 ? R : 1) * GSR_GROW_F * 4);
 }
-size_t gsr_backward_scratch_bytes(int64_t R, int W, int H) { return bwd_scratch_layout(R, W, H).bytes; }
 
 // Phase 1 shared by gsr_forward_geometry, gsr_forward and gsr_forward_params: `a` carries the inputs, the outputs inside the
 // geometry buffer are filled in here.  launch_geometry enqueues the two kernels, wait_geometry returns R.
@@ -247,7 +238,7 @@ static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_byte
 static int wait_geometry(const GeometryWait& w, int64_t* num_rendered_host, hipStream_t s)
 {
     uint32_t total = 0;
-    if (!w.mail || !mailbox_wait(w.mail_host, w.seq, &total)) {
+    if (!w.mail || !mailbox_wait(w.mail_host, w.seq, &total, s)) {
         hipError_t e = hipMemcpyAsync(&total, w.total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(-100, "forward_geometry: %s", hipGetErrorString(e));
@@ -396,11 +387,8 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
     {
         StageTimer t(GSR_STAGE_RENDER_FWD, s);
         const uint32_t* order = (R > 0 && gsr_variant("BIN", 1)) ? (const uint32_t*)(b + B.order) : nullptr;
-        const bool lists = R > 0 && gsr_block_lists_enabled();
-        if (lists) hipMemsetAsync(b + B.bmask, 0, (size_t)R * 4, s);  // one byte per (instance slot, quadrant); the walk sets the used ones
         gsr_launch_render_forward(W, H, ranges, point_list, (const float*)(g + G.splat), background, (float*)(im + I.final_T),
-                                  (uint32_t*)(im + I.n_contrib), out_color, order, lists ? (uint2*)(b + B.blist) : nullptr,
-                                  lists ? (uint32_t*)(b + B.bcount) : nullptr, lists ? (uint8_t*)(b + B.bmask) : nullptr, s);
+                                  (uint32_t*)(im + I.n_contrib), out_color, order, s);
     }
     return check_hip("forward_render");
 }
@@ -492,19 +480,7 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     const char* b = (const char*)binning_buffer;
     const char* im = (const char*)image_buffer;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-    const bool lists = gsr_block_lists_enabled();
-    const BwdScratch S = bwd_scratch_layout(R, W, H);
-    char* sc = (char*)scratch;
-    if (R > 0 && lists) {
-        // Gaussian-per-lane blend backward over the per-block lists the forward left in the binning buffer
-        StageTimer t(GSR_STAGE_RENDER_BWD, s);
-        gsr_launch_row_scan((uint32_t)R, (const uint8_t*)(b + B.bmask), (uint32_t*)(sc + S.sums), (uint32_t*)(sc + S.offsets),
-                            (uint32_t*)(sc + S.total), (uint32_t*)(sc + S.rowinfo), (uint32_t*)(sc + S.queues), s);
-        gsr_launch_render_backward_skew(W, H, (const uint32_t*)(b + B.order), (const uint32_t*)(im + I.ranges), (const uint2*)(b + B.blist),
-                                        (const uint32_t*)(b + B.bcount), (const uint32_t*)(sc + S.rowinfo), (const float*)(g + G.splat),
-                                        background, (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
-                                        (float*)(sc + S.rows), (uint32_t*)(sc + S.queues), s);
-    } else if (R > 0) {
+    if (R > 0) {
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));
         const bool in_b = !gsr_variant("BIN", 1) && gsr_sort_result_in_b(end_bit);
         const uint32_t* point_list = (const uint32_t*)(b + (in_b ? B.vals_b : B.vals_a));
@@ -518,8 +494,7 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     a.tiles_touched = (const uint32_t*)(g + G.tiles_touched);
     a.point_offsets = (const uint32_t*)(g + G.point_offsets);
     a.row_offsets = (const uint32_t*)(g + G.row_offsets);
-    a.grad_rows = (const float*)(sc + S.rows);
-    a.rowinfo = (R > 0 && lists) ? (const uint32_t*)(sc + S.rowinfo) : nullptr;
+    a.grad_rows = (const float*)scratch;
     { StageTimer t(GSR_STAGE_GAUSS_BWD, s); gsr_launch_gaussian_backward(a, s); }
     return check_hip("backward");
 }
@@ -837,22 +812,6 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
         if (n_contrib) hipMemcpyAsync(n_contrib, im + I.n_contrib, N * 4, hipMemcpyDeviceToDevice, s);
     }
     return check_hip("debug_export");
-}
-
-int gsr_debug_export_blocks(int P, int64_t R, int W, int H, const void* binning_buffer, uint32_t* blist, uint32_t* bcount,
-                            uint8_t* bmask, void* stream)
-{
-    hipStream_t s = (hipStream_t)stream;
-    if (P == 0 || R <= 0) return 0;
-    if (!binning_buffer) return fail(-1, "NULL required pointer");
-    if (!gsr_block_lists_enabled()) return fail(-2, "block lists are disabled (GSR_BLK=0)");
-    const BinLayout B = gsr_bin_layout((long)R, P, W, H);
-    const char* b = (const char*)binning_buffer;
-    const size_t T = (size_t)((W + GSR_TILE_X - 1) / GSR_TILE_X) * ((H + GSR_TILE_Y - 1) / GSR_TILE_Y);
-    if (blist) hipMemcpyAsync(blist, b + B.blist, (size_t)R * 4 * 8, hipMemcpyDeviceToDevice, s);
-    if (bcount) hipMemcpyAsync(bcount, b + B.bcount, T * 4 * 4, hipMemcpyDeviceToDevice, s);
-    if (bmask) hipMemcpyAsync(bmask, b + B.bmask, (size_t)R * 4, hipMemcpyDeviceToDevice, s);
-    return check_hip("debug_export_blocks");
 }
 
 void gsr_profile_enable(int on)

@@ -49,10 +49,6 @@ struct ImageLayout {
 
 struct BinLayout {
     size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, band, fixed_bytes, bytes;
-    // per-8x8-block lists written by the forward blend for the backward (render_backward_skew.hip): blist = uint2 {Gaussian id,
-    // position in the tile's list} per (block, entry) the forward found it may blend, 4 regions of n_tile entries per tile at
-    // 4 * ranges[tile].x; bcount = entries per block [4 * T]; bmask = one byte per (instance slot, quadrant) [4 * R]
-    size_t blist, bcount, bmask;
     uint32_t sort_blocks;
 };
 
@@ -132,13 +128,6 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
     L.vals_a = o; o = gsr_align(o + r * 4);
     L.vals_b = o; o = gsr_align(o + r * 4);
     L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
-    {
-        size_t t = (size_t)((W + GSR_TILE_X - 1) / GSR_TILE_X) * ((H + GSR_TILE_Y - 1) / GSR_TILE_Y);
-        if (t == 0) t = 1;
-        L.blist = o; o = gsr_align(o + 4 * r * 8);
-        L.bcount = o; o = gsr_align(o + 4 * t * 4);
-        L.bmask = o; o = gsr_align(o + 4 * r);
-    }
     L.bytes = o;
     return L;
 }
@@ -199,22 +188,13 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
                                   uint32_t* ranges, const uint32_t* band_count, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list,
                                   uint64_t* keys_sorted, hipStream_t s);
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
-// blist / bcount / bmask: per-block lists for the skewed backward (NULL: not wanted)
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
-                               uint2* blist, uint32_t* bcount, uint8_t* bmask, hipStream_t s);
+                               hipStream_t s);
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
                                 const uint32_t* order, float* grad_rows, hipStream_t s);
-size_t gsr_row_scan_blocks(int64_t R);
-size_t gsr_skew_queue_bytes();
-void gsr_launch_row_scan(uint32_t R, const uint8_t* bmask, uint32_t* sums, uint32_t* offsets, uint32_t* total, uint32_t* rowinfo,
-                         uint32_t* queue_heads, hipStream_t s);
-void gsr_launch_render_backward_skew(int W, int H, const uint32_t* order, const uint32_t* ranges, const uint2* blist, const uint32_t* bcount,
-                                     const uint32_t* rowinfo, const float* splat, const float* bg, const float* final_T,
-                                     const uint32_t* n_contrib, const float* dL_dpix, float* grad_rows, uint32_t* queue_heads, hipStream_t s);
 int gsr_variant(const char* name, int dflt);  // experiment switch read from the environment (GSR_<name>)
-bool gsr_block_lists_enabled();               // per-8x8-block lists in the forward + Gaussian-per-lane backward
 bool gsr_cull_enabled();                      // tile lists without the instances the splat's alpha >= 1/255 ellipse cannot reach
 struct GaussBackwardArgs {
     int P, D, M, W, H;
@@ -224,7 +204,6 @@ struct GaussBackwardArgs {
     float scale_modifier, tan_fovx, tan_fovy;
     int has_shs, has_scales;
     const float* grad_rows;
-    const uint32_t* rowinfo;  // row numbering of render_backward_skew.hip, or NULL (one finished row per instance slot)
     float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
     // raw-parameter mode (gsr_backward_params): scales / rotations are pre-activation, gradients are w.r.t. the raw
     // parameters, dL_dsh is split into dL_dfeatures_dc / dL_dfeatures_rest; dL_dcolors / dL_dcov3D may be NULL

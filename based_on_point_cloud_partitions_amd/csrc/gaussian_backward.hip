@@ -29,10 +29,6 @@ struct GaussBackwardPtrs {
     const float* __restrict__ projmatrix; const float* __restrict__ campos; const int* __restrict__ radii;
     const uint8_t* __restrict__ clamped; const float* __restrict__ splat; const uint32_t* __restrict__ tiles_touched;
     const float* __restrict__ grad_rows; const uint32_t* __restrict__ point_offsets; const uint32_t* __restrict__ row_offsets;
-    // non-NULL: rows are numbered by rowinfo (render_backward_skew.hip: one row per marked (instance slot, quadrant) pair, raw
-    // moments); NULL: one finished row per instance slot (render_backward.hip)
-    const uint32_t* __restrict__ rowinfo;
-    float half_w, half_h;
     float* __restrict__ dL_dmeans2D; float* __restrict__ dL_dcolors; float* __restrict__ dL_dopacity;
     float* __restrict__ dL_dmeans3D; float* __restrict__ dL_dcov3D; float* __restrict__ dL_dsh; float* __restrict__ dL_dscales;
     float* __restrict__ dL_drots;
@@ -84,27 +80,13 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     {
         const int first = blockIdx.x * BS, last = min(a.P, first + BS);
         uint32_t begin, end, my_off = 0, my_n = 0;
-        if (a.rowinfo) {  // rows numbered by rowinfo over the instance slots (render_backward_skew.hip)
-            begin = first == 0 ? 0u : a.point_offsets[first - 1];
-            end = a.point_offsets[last - 1];
-            if (visible) {
-                my_off = __float_as_uint(a.splat[(size_t)idx * GSR_SPLAT_F + SP_OFFS]);
-                my_n = a.tiles_touched[idx];
-            }
-            begin = a.rowinfo[begin] >> 4;
-            end = a.rowinfo[end] >> 4;
-            if (visible) {
-                const uint32_t r0 = a.rowinfo[my_off] >> 4, r1 = a.rowinfo[my_off + my_n] >> 4;
-                my_off = r0; my_n = r1 - r0;
-            }
-        } else {      // one row per reachable instance, numbered by the preprocess kernel's tile masks (render_backward.hip)
-            begin = first == 0 ? 0u : a.row_offsets[first - 1];
-            end = a.row_offsets[last - 1];
-            if (visible) {
-                const float4 q3 = *reinterpret_cast<const float4*>(a.splat + (size_t)idx * GSR_SPLAT_F + 12);
-                my_off = __float_as_uint(q3.x);
-                my_n = gsr_splat_rows(__float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w), a.tiles_touched[idx]);
-            }
+        // one row per reachable instance, numbered by the preprocess kernel's tile masks (render_backward.hip)
+        begin = first == 0 ? 0u : a.row_offsets[first - 1];
+        end = a.row_offsets[last - 1];
+        if (visible) {
+            const float4 q3 = *reinterpret_cast<const float4*>(a.splat + (size_t)idx * GSR_SPLAT_F + 12);
+            my_off = __float_as_uint(q3.x);
+            my_n = gsr_splat_rows(__float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w), a.tiles_touched[idx]);
         }
         const uint32_t CH = DIRECT ? (uint32_t)(RK * BS) : (uint32_t)a.lds_floats / GSR_GROW_F;  // rows per chunk
         float4* s_rows = reinterpret_cast<float4*>(s_tile);
@@ -145,18 +127,6 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
         }
     }
 
-    if (a.rowinfo && visible) {
-        // the rows held raw moments (S w dx, S w dy, S w dx^2, S w dx dy, S w dy^2, S w, S alpha T dL/dpixel): apply the
-        // per-Gaussian factors of backward.cu:538-554 once, to the sums
-        const float4 q0 = *reinterpret_cast<const float4*>(a.splat + (size_t)idx * GSR_SPLAT_F);
-        const float4 q1 = *reinterpret_cast<const float4*>(a.splat + (size_t)idx * GSR_SPLAT_F + 4);
-        const float cx = q0.z, cy = q0.w, cz = q1.x, op = q1.y;
-        const float s1 = g[0], s2 = g[1];
-        g[GR_MX] = op * (-cx * s1 - cy * s2) * a.half_w;
-        g[GR_MY] = op * (-cz * s2 - cy * s1) * a.half_h;
-        const float hop = -0.5f * op;
-        g[GR_CX] = hop * g[2]; g[GR_CY] = hop * g[3]; g[GR_CW] = hop * g[4];
-    }
     if (RAW && !DIRECT) {
         sh_cols_load(a.features_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
         if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
@@ -501,7 +471,7 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.means3D = a.means3D; p.shs = a.shs; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_in = a.cov3D_in;
     p.viewmatrix = a.viewmatrix; p.projmatrix = a.projmatrix; p.campos = a.campos; p.radii = a.radii; p.clamped = a.clamped;
     p.splat = a.splat; p.tiles_touched = a.tiles_touched; p.grad_rows = a.grad_rows; p.point_offsets = a.point_offsets;
-    p.row_offsets = a.row_offsets; p.rowinfo = a.rowinfo; p.half_w = 0.5f * a.W; p.half_h = 0.5f * a.H;
+    p.row_offsets = a.row_offsets;
     p.dL_dmeans2D = a.dL_dmeans2D; p.dL_dcolors = a.dL_dcolors; p.dL_dopacity = a.dL_dopacity; p.dL_dmeans3D = a.dL_dmeans3D;
     p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscales = a.dL_dscales; p.dL_drots = a.dL_drots;
     p.features_dc = a.features_dc; p.features_rest = a.features_rest;

@@ -181,8 +181,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
     const int my_slot = lane < 8 ? (4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1)) : 8;
 
     for (int i = 0; i < rounds; i++) {
-        // gather this batch's records (back to front); entries the tile cannot see at all (gsr_tile_cannot_touch) get their
-        // zero gradient row right here and are dropped from the walk
+        // gather this batch's records (back to front); instances whose tile the splat cannot reach own no gradient row
+        // (gsr_reach_mask, preprocess) and are dropped from the walk
         const uint32_t progress = (uint32_t)i * BATCH + tid;
         bool keep = false;
         float4 q0, q1, q2;
@@ -199,8 +199,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) r
             const uint32_t tilepos = (by - mny) * (mxx - mnx) + (bx - mnx);
             pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
             if (__float_as_uint(q3.w) == 0u) {
-                // the preprocess kernel has applied gsr_tile_cannot_touch to every tile of the rectangle: an unreachable instance
-                // owns no row and is dropped here; a reachable one is numbered by its rank among the reachable tiles
+                // the preprocess kernel has applied gsr_reach_mask to the rectangle: an unreachable instance owns no row and is
+                // dropped here; a reachable one is numbered by its rank among the reachable tiles
                 const unsigned long long mask = ((unsigned long long)__float_as_uint(q3.z) << 32) | __float_as_uint(q3.y);
                 keep = (mask >> tilepos) & 1ull;
                 row = __float_as_uint(q3.x) + (uint32_t)__popcll(mask & ((1ull << tilepos) - 1ull));

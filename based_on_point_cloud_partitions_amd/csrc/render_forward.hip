@@ -10,28 +10,21 @@
 // below ("CONTRACT-FMA"), exp is gsr_expf -> final_T, n_contrib and out_color are bit-identical.
 // The `pthr` test is a pure shortcut: power < ln(1/(255*opacity)) - 1e-3 implies alpha < 1/255 for any
 // exp accurate to 1e-6, so skipping the exp there cannot change a decision.
-//
-// LISTS: the walk also records, per 8x8 block (= wave), the list entries that blended at least one of its pixels and
-// appends them -- {Gaussian id, position in the tile's list}, in list order -- to the block's list; one byte per
-// (instance slot, quadrant) marks the (Gaussian, block) pairs that will own a gradient row.  The backward
-// (render_backward_skew.hip) walks these lists instead of re-deriving them: exactly the pairs it has work for.
 #include "common.h"
 
 namespace {
 
-template <bool LISTS, bool QUAD>
+template <bool QUAD>
 __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, int gy, int wave8x8, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list,
                                                              const float* __restrict__ splat, const float* __restrict__ bg,
                                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                             float* __restrict__ out_color, uint2* __restrict__ blist,
-                                                             uint32_t* __restrict__ bcount, uint8_t* __restrict__ bmask)
+                                                             float* __restrict__ out_color)
 {
     __shared__ float4 s_a[260];  // mx, my, conic.x, conic.y          (+4: padding entries for the unrolled walk)
     __shared__ float4 s_b[260];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
     __shared__ float4 s_c[256];  // r, g, b, Gaussian id (uint bits)
-    __shared__ uint32_t s_slot[LISTS ? 256 : 1];  // instance slot (emission order) of the staged entry
     __shared__ int s_done[4];
     __shared__ int s_wcnt[4];    // entries each wave keeps after the tile-level rejection
     __shared__ unsigned long long s_qm[QUAD ? 4 : 1][4];  // QUAD: per blend wave (quadrant), per staging wave: the staged entries that can reach it
@@ -55,8 +48,6 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
-    uint32_t bcnt = 0;  // entries appended to this wave's block list (wave-uniform)
-    uint2* my_list = LISTS ? blist + 4 * (size_t)r0 + (size_t)wave * (size_t)total : nullptr;
     // `done` is encoded in px: a finished (or outside) pixel is parked at x = PARKED, which drives its `power` to
     // -inf/NaN so the single range test of the hot loop rejects it -- no `done` mask, no EXEC branch per entry.
     constexpr float PARKED = 1e30f;
@@ -149,7 +140,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
         bool keep = false;
         float4 q0, q1, q2;
         float pthr = 0.f;
-        uint32_t id = 0, slot = 0;
+        uint32_t id = 0;
         if (progress < total) {
             id = point_list[r0 + progress];
             const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
@@ -157,11 +148,6 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             // conservative skip threshold on `power` (see header); opacity <= 0 or NaN never skips
             pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
             keep = !gsr_tile_cannot_touch(q0.x, q0.y, q0.z, q0.w, q1.x, pthr, tile_x0, tile_y0);
-            if (LISTS && keep) {  // instance slot = the Gaussian's first slot + position of this tile in its rectangle
-                uint32_t mnx, mny, mxx, mxy;
-                gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
-                slot = __float_as_uint(q2.w) + (by - mny) * (mxx - mnx) + (bx - mnx);
-            }
         }
         const unsigned long long bal = __ballot(keep);
         if (lane == 0) { s_done[wave] = wave_done; s_wcnt[wave] = __popcll(bal); }
@@ -178,109 +164,50 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             // exp then never sees an argument outside [-80, 0]
             s_b[pos] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress));
             s_c[pos] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
-            if (LISTS) s_slot[pos] = slot;
         }
         if (tid < 4) {  // padding entries that can never pass the range test (walk runs in groups of 4, no bounds checks)
             s_a[kept + tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
             s_b[kept + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
         }
         __syncthreads();
-        if (!LISTS) {
-            if (!wave_done) {
-                for (int j0 = 0; j0 < kept; j0 += 4) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int j = j0 + u;
-                        const float4 a = s_a[j];
-                        const float4 b = s_b[j];
-                        const float dx = a.x - px, dy = a.y - pixf_y;
-                        // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
-                        const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
-                        const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
-                        // one compare (parked pixels and padding entries give -inf / NaN / pthr = inf and fail it); power > 0 is
-                        // left to the exact path
-                        const bool maybe = power >= b.z;
-                        if (gsr_any(maybe)) {  // wave-uniform; rare relative to the skip
-                            if (maybe && px != PARKED && power <= 0.0f) {
-                                const float alpha = fminf(0.99f, b.y * gsr_expf_inrange(power));
-                                if (alpha >= 1.0f / 255.0f) {
-                                    const float test_T = T * (1.0f - alpha);
-                                    if (test_T < 0.0001f) {
-                                        px = PARKED;  // done
-                                    } else {
-                                        const float4 c = s_c[j];
-                                        // CONTRACT-FMA: C += (f*alpha)*T
-                                        C0 = __builtin_fmaf(c.x * alpha, T, C0);
-                                        C1 = __builtin_fmaf(c.y * alpha, T, C1);
-                                        C2 = __builtin_fmaf(c.z * alpha, T, C2);
-                                        T = test_T;
-                                        last_contributor = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (!gsr_any(px != PARKED)) { wave_done = true; break; }
-                }
-            }
-            continue;
-        }
-        // LISTS: the same walk, 64 entries at a time with one bit per entry for the block's list
         if (!wave_done) {
-            for (int jb = 0; jb < kept && !wave_done; jb += 64) {  // 64 entries at a time: one bit per entry for the block list
-                unsigned long long mbits = 0ull;
-                const int jend = min(kept, jb + 64);
-                for (int j0 = jb; j0 < jend; j0 += 4) {
+            for (int j0 = 0; j0 < kept; j0 += 4) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int j = j0 + u;
-                        const float4 a = s_a[j];
-                        const float4 b = s_b[j];
-                        const float dx = a.x - px, dy = a.y - pixf_y;
-                        // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
-                        const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
-                        const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
-                        // one compare (parked pixels and padding entries give -inf / NaN / pthr = inf and fail it); power > 0 is
-                        // left to the exact path
-                        const bool maybe = power >= b.z;
-                        if (gsr_any(maybe)) {  // wave-uniform; rare relative to the skip
-                            const uint32_t kp1 = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
-                            if (maybe && px != PARKED && power <= 0.0f) {
-                                const float alpha = fminf(0.99f, b.y * gsr_expf_inrange(power));
-                                if (alpha >= 1.0f / 255.0f) {
-                                    const float test_T = T * (1.0f - alpha);
-                                    if (test_T < 0.0001f) {
-                                        px = PARKED;  // done
-                                    } else {
-                                        const float4 c = s_c[j];
-                                        // CONTRACT-FMA: C += (f*alpha)*T
-                                        C0 = __builtin_fmaf(c.x * alpha, T, C0);
-                                        C1 = __builtin_fmaf(c.y * alpha, T, C1);
-                                        C2 = __builtin_fmaf(c.z * alpha, T, C2);
-                                        T = test_T;
-                                        last_contributor = kp1;
-                                    }
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + u;
+                    const float4 a = s_a[j];
+                    const float4 b = s_b[j];
+                    const float dx = a.x - px, dy = a.y - pixf_y;
+                    // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
+                    const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
+                    const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
+                    // one compare (parked pixels and padding entries give -inf / NaN / pthr = inf and fail it); power > 0 is
+                    // left to the exact path
+                    const bool maybe = power >= b.z;
+                    if (gsr_any(maybe)) {  // wave-uniform; rare relative to the skip
+                        if (maybe && px != PARKED && power <= 0.0f) {
+                            const float alpha = fminf(0.99f, b.y * gsr_expf_inrange(power));
+                            if (alpha >= 1.0f / 255.0f) {
+                                const float test_T = T * (1.0f - alpha);
+                                if (test_T < 0.0001f) {
+                                    px = PARKED;  // done
+                                } else {
+                                    const float4 c = s_c[j];
+                                    // CONTRACT-FMA: C += (f*alpha)*T
+                                    C0 = __builtin_fmaf(c.x * alpha, T, C0);
+                                    C1 = __builtin_fmaf(c.y * alpha, T, C1);
+                                    C2 = __builtin_fmaf(c.z * alpha, T, C2);
+                                    T = test_T;
+                                    last_contributor = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
                                 }
                             }
-                            // the entry blended a pixel of this block iff some lane's last contributor is now this entry
-                            if (LISTS && gsr_any(last_contributor == kp1)) mbits |= 1ull << (j & 63);
                         }
                     }
-                    if (!gsr_any(px != PARKED)) { wave_done = true; break; }
                 }
-                if (LISTS && mbits != 0ull) {  // append the marked entries of this chunk to the block's list, order preserved
-                    if ((mbits >> lane) & 1ull) {
-                        const int e = jb + lane;
-                        const uint32_t pos = bcnt + (uint32_t)__popcll(mbits & ((1ull << lane) - 1ull));
-                        my_list[pos] = make_uint2(__float_as_uint(s_c[e].w), __float_as_uint(s_b[e].w));
-                        bmask[4 * (size_t)s_slot[e] + wave] = 1;
-                    }
-                    bcnt += (uint32_t)__popcll(mbits);
-                }
+                if (!gsr_any(px != PARKED)) { wave_done = true; break; }
             }
         }
     }
-    if (LISTS && lane == 0) bcount[4 * tile + wave] = bcnt;
     if (inside) {
         const size_t pix_id = (size_t)W * pix_y + pix_x;
         const size_t plane = (size_t)H * W;
@@ -296,18 +223,15 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
 
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
-                               uint2* blist, uint32_t* bcount, uint8_t* bmask, hipStream_t s)
+                               hipStream_t s)
 {
     if (!gsr_variant("LPT", 1)) order = nullptr;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int wave8x8 = gsr_variant("WAVE8X8", 1);
-    if (blist && wave8x8)  // the block lists are per 8x8 block = per wave of the 8x8 layout
-        hipLaunchKernelGGL((render_forward_kernel<true, false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
-                           final_T, n_contrib, out_color, blist, bcount, bmask);
-    else if (wave8x8 && gsr_variant("QUAD", 1))
-        hipLaunchKernelGGL((render_forward_kernel<false, true>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, gsr_variant("QUAD", 1) == 2 ? 2 : 1, order, ranges, point_list, splat, bg,
-                           final_T, n_contrib, out_color, nullptr, nullptr, nullptr);
+    if (wave8x8 && gsr_variant("QUAD", 1))
+        hipLaunchKernelGGL((render_forward_kernel<true>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, gsr_variant("QUAD", 1) == 2 ? 2 : 1, order, ranges, point_list, splat, bg,
+                           final_T, n_contrib, out_color);
     else
-        hipLaunchKernelGGL((render_forward_kernel<false, false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
-                           final_T, n_contrib, out_color, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((render_forward_kernel<false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
+                           final_T, n_contrib, out_color);
 }

@@ -7,6 +7,7 @@ submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py
 gaussian_renderer/__init__.py:14,36-93 works unchanged when `dropin/` is on PYTHONPATH.
 """
 import ctypes
+import threading
 from typing import NamedTuple
 
 import torch
@@ -21,14 +22,21 @@ NUM_CHANNELS = 3  # cuda_rasterizer/config.h:14
 # hundred iterations, so the table is kept small (oldest keys dropped).
 _R_SEEN = {}
 _R_SEEN_MAX = 64
+_R_SEEN_LOCK = threading.Lock()  # autograd runs backward (and users may run forwards) from several host threads
 
 
 def _remember_rendered(key, rendered):
-    if rendered > _R_SEEN.get(key, 0):
-        _R_SEEN.pop(key, None)
-        _R_SEEN[key] = rendered  # most recently raised key last
-        while len(_R_SEEN) > _R_SEEN_MAX:
-            _R_SEEN.pop(next(iter(_R_SEEN)))
+    with _R_SEEN_LOCK:
+        if rendered > _R_SEEN.get(key, 0):
+            _R_SEEN.pop(key, None)
+            _R_SEEN[key] = rendered  # most recently raised key last
+            while len(_R_SEEN) > _R_SEEN_MAX:
+                _R_SEEN.pop(next(iter(_R_SEEN)))
+
+
+def _guess_rendered(key):
+    with _R_SEEN_LOCK:
+        return _R_SEEN.get(key, 0)
 
 
 def _ptr(t):
@@ -93,7 +101,7 @@ def rasterize_gaussians_forward(background, means3D, colors, opacity, scales, ro
             geomBuffer = torch.empty(lib.gsr_geometry_bytes(P), **byte)
             imgBuffer = torch.empty(lib.gsr_image_bytes(W, H), **byte)
             key = (dev.index, P, W, H)
-            guess = _R_SEEN.get(key, 0)
+            guess = _guess_rendered(key)
             binningBuffer = torch.empty(lib.gsr_binning_bytes(guess + guess // 4, P, W, H) if guess > 0 else 0, **byte)
             R = ctypes.c_int64(0)
             s = _stream(dev)
@@ -308,21 +316,4 @@ def debug_export(P, R, W, H, geomBuffer, binningBuffer, imgBuffer):
                      "keys_sorted", "point_list", "ranges", "final_T", "n_contrib"]
             _lib.check(lib.gsr_debug_export(P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imgBuffer),
                                             *[_ptr(out[k]) for k in order], _stream(dev)), "gsr_debug_export")
-    return out
-
-
-def debug_export_blocks(P, R, W, H, binningBuffer):
-    """Copies the per-8x8-block lists the forward left for the backward (tests / inspection only): blist int32 [4R, 2]
-    ({Gaussian id, position in the tile's list}), bcount int32 [4T], bmask uint8 [4R]; layout in include/gsrast_mi355x.h."""
-    lib = _lib.load()
-    dev = binningBuffer.device
-    T = ((W + 15) // 16) * ((H + 15) // 16)
-    n = max(R, 1)
-    out = dict(blist=torch.zeros((4 * n, 2), dtype=torch.int32, device=dev)[:4 * R],
-               bcount=torch.zeros((4 * T,), dtype=torch.int32, device=dev),
-               bmask=torch.zeros((4 * n,), dtype=torch.uint8, device=dev)[:4 * R])
-    if P and R:
-        with torch.cuda.device(dev):
-            _lib.check(lib.gsr_debug_export_blocks(P, R, W, H, _ptr(binningBuffer), _ptr(out["blist"]), _ptr(out["bcount"]),
-                                                   _ptr(out["bmask"]), _stream(dev)), "gsr_debug_export_blocks")
     return out

@@ -17,7 +17,7 @@ import math
 import torch
 
 from . import _lib
-from .rasterizer import (NUM_CHANNELS, _R_SEEN, GaussianRasterizationSettings, GaussianRasterizer, _prep, _ptr, _remember_rendered,
+from .rasterizer import (NUM_CHANNELS, _guess_rendered, GaussianRasterizationSettings, GaussianRasterizer, _prep, _ptr, _remember_rendered,
                          _require_hip, _stream)
 
 
@@ -57,7 +57,7 @@ def rasterize_gaussian_params_forward(background, xyz, features_dc, features_res
             geomBuffer = torch.empty(lib.gsr_geometry_bytes(P), **byte)
             imgBuffer = torch.empty(lib.gsr_image_bytes(W, H), **byte)
             key = (dev.index, P, W, H)
-            guess = _R_SEEN.get(key, 0)
+            guess = _guess_rendered(key)
             binningBuffer = torch.empty(lib.gsr_binning_bytes(guess + guess // 4, P, W, H) if guess > 0 else 0, **byte)
             R = ctypes.c_int64(0)
             s = _stream(dev)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 13
+#define GSR_ABI_VERSION 14
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -211,19 +211,10 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
                      uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_offsets, uint64_t* keys_sorted,
                      uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, void* stream);
 
-/* Test/inspection hook for the per-8x8-block lists the forward blend leaves in the binning buffer for the backward
- * (no reference counterpart: the reference's backward re-walks the tile lists, backward.cu:399-557).  The four 8x8 blocks of
- * tile t (quadrant q = 2 * (y half) + (x half)) own the regions blist[4 * ranges[t].x + q * n_t ...) of n_t = ranges[t].y -
- * ranges[t].x entries each; bcount[4 * t + q] of them are valid: {Gaussian id, position in the tile's list} of every list
- * entry that blended at least one pixel of the block, in list order.  bmask[4 * slot + q] = 1 for the same pairs, indexed by
- * the instance's emission slot (point_offsets[g - 1] + position of the tile in g's rectangle).  Any output may be NULL;
- * blist is uint32[4 * R][2], bcount uint32[4 * T], bmask uint8[4 * R]. */
-int gsr_debug_export_blocks(int P, int64_t R, int W, int H, const void* binning_buffer, uint32_t* blist, uint32_t* bcount,
-                            uint8_t* bmask, void* stream);
-
 /* Overrides an experiment switch (environment GSR_<NAME>) for this process: A/B measurements and the tests
- * that keep the alternative kernels covered.  No switch changes a result beyond the documented tolerances. */
-void gsr_set_variant(const char* name, int value);
+ * that keep the alternative kernels covered.  No switch changes a result beyond the documented tolerances.
+ * Returns 0, or -1 when the switch cannot be stored (NULL / name of 24+ characters / table of 64 switches full). */
+int gsr_set_variant(const char* name, int value);
 int gsr_get_variant(const char* name, int default_value);
 
 /* Stand-alone stable LSD radix sort of (u64,u32) pairs on bits [0,end_bit) (the binning sort, exported for

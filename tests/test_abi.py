@@ -39,6 +39,23 @@ def test_size_queries():
     assert lib.gsr_backward_scratch_bytes(1000, 64, 64) >= 48000
     assert lib.gsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 8
     assert lib.gsr_knn_scratch_bytes(1000) > 0 and lib.gsr_sort_scratch_bytes(1000) > 0
+    # the R-dependent part of the binning buffer: (depth, id) pairs + a second u64 array + point_list + the radix path's
+    # second value array and block histograms = 24 B per instance + 4.25 B for the radix path, nothing else
+    P, W, H = 500_000, 1920, 1080
+    per_instance = (lib.gsr_binning_bytes(40_000_000, P, W, H) - lib.gsr_binning_bytes(0, P, W, H)) / 40_000_000
+    assert 24.0 <= per_instance <= 28.5, per_instance
+    assert lib.gsr_backward_scratch_bytes(40_000_000, W, H) <= 48 * 40_000_000 + 256
+
+
+def test_set_variant_reports_failure():
+    from based_on_point_cloud_partitions_amd import _lib
+
+    lib = _lib.load()
+    assert lib.gsr_set_variant(b"ABI_TEST_SWITCH", 3) == 0 and lib.gsr_get_variant(b"ABI_TEST_SWITCH", 0) == 3
+    assert lib.gsr_set_variant(b"A_NAME_OF_MORE_THAN_TWENTY_THREE_CHARACTERS", 1) == -1
+    assert b"cannot be stored" in lib.gsr_last_error()
+    with pytest.raises(_lib.GsrError):
+        _lib.set_variant("A_NAME_OF_MORE_THAN_TWENTY_THREE_CHARACTERS", 1)
 
 
 def test_operator_surface_matches_reference_names():

@@ -10,7 +10,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = dict(QUAD=1, CULL=1, BIN=2, LPT=1, MAILBOX=1, BWD_RS=1, BWD_FASTEXP=1, BWD_BATCH=128, KEYS=0, WAVE8X8=1, EARLY=1, BANDS=8,
-                GB_BLOCK=128, BLK=0, PRE_DIRECT=1, GB_DIRECT=1, GB_RK=1)
+                GB_BLOCK=128, PRE_DIRECT=1, GB_DIRECT=1, GB_RK=1)
 ALTERNATIVES = [
     dict(QUAD=0),                 # every wave walks the whole tile list
     dict(QUAD=0, CULL=0),         # ... over the reference's lists

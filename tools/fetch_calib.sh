@@ -4,6 +4,8 @@ tag=${1:-calib}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
+# the probe is built from its source here (no binaries in the repository)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/fetch_calib tools/fetch_calib.hip || exit 2
 ./tools/fetch_calib > $out/fetch_calib.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out -o fc -- ./tools/fetch_calib > $out/fc.log 2>&1 || { tail -5 $out/fc.log; exit 2; }
 python3 - <<PY >> $out/fetch_calib.txt
