@@ -418,6 +418,10 @@ __device__ __forceinline__ uint32_t gsr_splat_rows(uint32_t mask_lo, uint32_t ma
     return big ? tiles_touched : (uint32_t)(__popc(mask_lo) + __popc(mask_hi));
 }
 
+// relative margin of the reach tests as a function of the conic's conditioning kappa = cx cz / det (see gsr_reach_mask):
+// 1e-3 for a round splat (the value every measurement of rounds 1-2 was taken with), +2e-6 per unit of kappa
+#define GSR_REACH_REL(kappa) (1e-3f + 2e-6f * (kappa))
+
 // Which tiles of a splat's rectangle [mnx, mxx) x [mny, mxy) (at most 64 tiles) can its alpha >= 1/255 ellipse reach?  Bit
 // (ty - mny) * (mxx - mnx) + (tx - mnx) is set if any pixel centre of tile (tx, ty) may satisfy
 // q = cx u^2 + 2 cy u v + cz v^2 <= t, t = 2 ln(255 opacity), (u, v) = pixel - mean.  CONSERVATIVE (margins far above the fp32
@@ -432,14 +436,21 @@ __device__ __forceinline__ unsigned long long gsr_reach_mask(float mx, float my,
     const uint32_t w = mxx - mnx, h = mxy - mny, n = w * h;
     const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     if (!(opacity > 0.f)) return all;                       // opacity <= 0 or NaN: everything is left to the exact path
-    float t = 2.0f * __logf(255.0f * opacity);
-    t = t + (2e-3f * fabsf(t) + 5e-3f);                     // margin of the blend kernels' own skip threshold and then some
-    if (t < 0.f) return 0ull;                               // alpha < 1/255 even at the centre
+    const float t0 = 2.0f * __logf(255.0f * opacity);
+    if (t0 + (2e-3f * fabsf(t0) + 5e-3f) < 0.f) return 0ull;  // alpha < 1/255 even at the centre
     const float det = cx * cz - cy * cy;
     if (!(cx > 0.f) || !(cz > 0.f) || !(det > 0.f) || !(det < INFINITY)) return all;  // not an ellipse: no statement
     // hardware reciprocal / square root (1 ulp): their error is orders of magnitude below the margins
     const float inv_cx = __builtin_amdgcn_rcpf(cx), inv_det = __builtin_amdgcn_rcpf(det);
-    const float vmax = __builtin_amdgcn_sqrtf(cx * t * inv_det) * 1.001f + 0.02f;   // |v| extent of the ellipse
+    // Conditioning.  kappa = cx cz / det >= 1 grows with the square of the aspect ratio of a diagonal splat.  The fp32 products behind
+    // det cancel (relative error ~1.2e-7 kappa), and so do the three terms of q in the blend kernels' own per-pixel evaluation
+    // (cx dx^2 + cz dy^2 <= 2 kappa q): every margin below is therefore relative to GSR_REACH_REL(kappa), and beyond kappa = 4096
+    // (a 130:1 needle on the diagonal) no statement is made at all.
+    const float kappa = (cx * cz) * inv_det;
+    if (!(kappa <= 4096.0f)) return all;
+    const float rel = GSR_REACH_REL(kappa);
+    const float t = t0 + (2.0f * rel * fabsf(t0) + 5e-3f);  // margin of the blend kernels' own skip threshold and then some
+    const float vmax = __builtin_amdgcn_sqrtf(cx * t * inv_det) * (1.0f + rel) + 0.02f;   // |v| extent of the ellipse
     const float umax_g = __builtin_amdgcn_sqrtf(cz * t * inv_det);                  // |u| extent; it is reached at v = -+(cy / cz) * umax_g
     const float vstar = -(cy * __builtin_amdgcn_rcpf(cz)) * umax_g;                 // v of the right-most point (left-most: -vstar)
     const float slope = -cy * inv_cx;
@@ -453,7 +464,7 @@ __device__ __forceinline__ unsigned long long gsr_reach_mask(float mx, float my,
         const float vr = fminf(fmaxf(vstar, vl), vh), vq = fminf(fmaxf(-vstar, vl), vh);
         const float dr = fmaxf(cx * t - det * vr * vr, 0.f), dq = fmaxf(cx * t - det * vq * vq, 0.f);
         const float ur = slope * vr + __builtin_amdgcn_sqrtf(dr) * inv_cx, ul = slope * vq - __builtin_amdgcn_sqrtf(dq) * inv_cx;
-        const float m = 0.02f + 1e-3f * (fabsf(ur) + fabsf(ul));
+        const float m = 0.02f + rel * (fabsf(ur) + fabsf(ul));
         // tiles whose pixel centres [16 tx, 16 tx + 15] meet [mx + ul - m, mx + ur + m]
         const float lo_f = ceilf((mx + ul - m - (float)(GSR_TILE_X - 1)) * (1.0f / GSR_TILE_X));
         const float hi_f = floorf((mx + ur + m) * (1.0f / GSR_TILE_X));
@@ -472,13 +483,16 @@ __device__ __forceinline__ unsigned long long gsr_reach_mask(float mx, float my,
 __device__ __forceinline__ uint32_t gsr_quad_mask(float mx, float my, float cx, float cy, float cz, float opacity, float x0, float y0)
 {
     if (!(opacity > 0.f)) return 15u;
-    float t = 2.0f * __logf(255.0f * opacity);
-    t = t + (2e-3f * fabsf(t) + 5e-3f);
-    if (t < 0.f) return 0u;
+    const float t0 = 2.0f * __logf(255.0f * opacity);
+    if (t0 + (2e-3f * fabsf(t0) + 5e-3f) < 0.f) return 0u;
     const float det = cx * cz - cy * cy;
     if (!(cx > 0.f) || !(cz > 0.f) || !(det > 0.f) || !(det < INFINITY)) return 15u;
     const float inv_cx = __builtin_amdgcn_rcpf(cx), inv_det = __builtin_amdgcn_rcpf(det);
-    const float vmax = __builtin_amdgcn_sqrtf(cx * t * inv_det) * 1.001f + 0.02f;
+    const float kappa = (cx * cz) * inv_det;  // conditioning: see gsr_reach_mask
+    if (!(kappa <= 4096.0f)) return 15u;
+    const float rel = GSR_REACH_REL(kappa);
+    const float t = t0 + (2.0f * rel * fabsf(t0) + 5e-3f);
+    const float vmax = __builtin_amdgcn_sqrtf(cx * t * inv_det) * (1.0f + rel) + 0.02f;
     const float vstar = -(cy * __builtin_amdgcn_rcpf(cz)) * __builtin_amdgcn_sqrtf(cz * t * inv_det);
     const float slope = -cy * inv_cx;
     uint32_t mask = 0;
@@ -489,7 +503,7 @@ __device__ __forceinline__ uint32_t gsr_quad_mask(float mx, float my, float cx, 
         const float vr = fminf(fmaxf(vstar, vl), vh), vq = fminf(fmaxf(-vstar, vl), vh);
         const float dr = fmaxf(cx * t - det * vr * vr, 0.f), dq = fmaxf(cx * t - det * vq * vq, 0.f);
         const float ur = slope * vr + __builtin_amdgcn_sqrtf(dr) * inv_cx, ul = slope * vq - __builtin_amdgcn_sqrtf(dq) * inv_cx;
-        const float m = 0.02f + 1e-3f * (fabsf(ur) + fabsf(ul));
+        const float m = 0.02f + rel * (fabsf(ur) + fabsf(ul));
         const float A = mx + ul - m, B = mx + ur + m;  // pixel centres the band's cut of the ellipse spans
         if (!(A > x0 + 7.0f) && !(B < x0)) mask |= 1u << (2 * band);
         if (!(A > x0 + 15.0f) && !(B < x0 + 8.0f)) mask |= 2u << (2 * band);

@@ -59,6 +59,63 @@ def dedup_first_lexicographic(rows):
     return rows[order[first]]
 
 
+def unpack_block(rows):
+    """[N,59] -> dict of GaussianModel's raw parameter tensors (`_xyz`, `_features_dc` [N,1,3], `_features_rest` [N,15,3], ...):
+    the inverse of pack_block, i.e. what load_ply builds (scene/gaussian_model.py:236-278)."""
+    N = rows.shape[0]
+    return dict(xyz=rows[:, 0:3].contiguous(), features_dc=rows[:, 3:6].reshape(N, 3, 1).transpose(1, 2).contiguous(),
+                features_rest=rows[:, 6:51].reshape(N, 3, 15).transpose(1, 2).contiguous(), opacity=rows[:, 51:52].contiguous(),
+                scaling=rows[:, 52:55].contiguous(), rotation=rows[:, 55:59].contiguous())
+
+
+def dynamic_bounding_box(index, origin_boxes, eps=1e-9):
+    """Crop box of partition `index` among axis-aligned `origin_boxes` [(minx, miny, maxx, maxy), ...]: a side stays closed only
+    where a neighbour -- a box sharing a boundary segment of non-zero length (find_adjacent_partitions,
+    scene/ptgs/shen_partition.py:165-186) -- has its opposite side on it; a side without neighbour is left open (None)
+    (dynamic_bounding_box, scene/ptgs/merge_partitions.py:10-57)."""
+    minx, miny, maxx, maxy = origin_boxes[index]
+    left = right = down = up = False
+    for j, (nx0, ny0, nx1, ny1) in enumerate(origin_boxes):
+        if j == index or (nx0, ny0, nx1, ny1) == (minx, miny, maxx, maxy):
+            continue
+        # intersection of the two rectangles must be a segment of non-zero length (not a corner, not an area)
+        ix0, ix1, iy0, iy1 = max(minx, nx0), min(maxx, nx1), max(miny, ny0), min(maxy, ny1)
+        if ix1 < ix0 or iy1 < iy0:
+            continue
+        w, h = ix1 - ix0, iy1 - iy0
+        if not ((w == 0) != (h == 0)):
+            continue
+        left |= abs(nx1 - minx) < eps
+        right |= abs(nx0 - maxx) < eps
+        down |= abs(ny1 - miny) < eps
+        up |= abs(ny0 - maxy) < eps
+    return (minx if left else None, miny if down else None, maxx if right else None, maxy if up else None)
+
+
+def all_gather_blocks(kept, group=None):
+    """The exchange step: every rank contributes its cropped [n_i, 59] block, every rank receives the concatenation in rank
+    (= partition) order.  Two collectives -- the counts, then ONE all-gather of the blocks padded to the largest count
+    (`all_gather_into_tensor`: a single RCCL call over xGMI, ~118 MB per rank at 500k Gaussians) -- and one host sync for the
+    counts.  Returns (rows [sum n_i, 59], counts list)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if kept.is_cuda and dist.get_backend(group) == "gloo":  # single-GPU rehearsals of the N > 1 path: gloo gathers host tensors
+        rows, counts = all_gather_blocks(kept.cpu(), group)
+        return rows.to(kept.device), counts
+    count = torch.tensor([kept.shape[0]], dtype=torch.int64, device=kept.device)
+    counts_t = torch.empty(world, dtype=torch.int64, device=kept.device)
+    dist.all_gather_into_tensor(counts_t, count, group=group)
+    counts = counts_t.tolist()
+    maxn = max(max(counts), 1)
+    padded = torch.zeros((maxn, ROW), dtype=kept.dtype, device=kept.device)
+    padded[:kept.shape[0]] = kept
+    gathered = torch.empty((world * maxn, ROW), dtype=kept.dtype, device=kept.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    gathered = gathered.view(world, maxn, ROW)
+    return torch.cat([gathered[r, :c] for r, c in enumerate(counts)], dim=0), counts
+
+
 def merge_partitions(block, box, group=None):
     """Collective: every rank passes its own [N_i, 59] block and crop box and receives the merged [N, 59] scene."""
     import torch.distributed as dist
@@ -66,15 +123,5 @@ def merge_partitions(block, box, group=None):
     kept = block[crop_mask(block[:, :3], box)].contiguous()
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return dedup_first_lexicographic(kept)
-    world = dist.get_world_size(group)
-    count = torch.tensor([kept.shape[0]], dtype=torch.int64, device=block.device)
-    counts = [torch.zeros_like(count) for _ in range(world)]
-    dist.all_gather(counts, count, group=group)
-    counts = [int(c.item()) for c in counts]
-    maxn = max(max(counts), 1)
-    padded = torch.zeros((maxn, ROW), dtype=block.dtype, device=block.device)
-    padded[:kept.shape[0]] = kept
-    gathered = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(gathered, padded, group=group)
-    allrows = torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)  # partition (= rank) order
+    allrows, _ = all_gather_blocks(kept, group)  # partition (= rank) order
     return dedup_first_lexicographic(allrows)

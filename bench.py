@@ -104,6 +104,7 @@ def cpu_baseline(cfg, g, cams, dL, n_steps=4):
         small[label + "_it_per_s"] = round(1.0 / (f + b), 2)
     oracle.set_threads(cores)
     return {"value": n_steps / (fwd + bwd), "unit": "it/s", "cores": cores, "kind": "port",
+            "build": "gcc -O3 -march=x86-64-v3 -fopenmp, OpenMP over Gaussians / tiles, parallel stable LSD radix sort (oracle/Makefile)",
             "sample": f"{n_steps} raster steps (cameras 0..{n_steps - 1} of the {cfg['P']}-Gaussian {cfg['W']}x{cfg['H']} workload): "
                       f"forward {fwd:.2f} s + backward {bwd:.2f} s in all, OpenMP over Gaussians/tiles; "
                       f"thread count chosen from one step each: {tried} s",
@@ -329,6 +330,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    # what the collective library itself saw: every rank contributes its number through one all-gather
+    ranks_seen = [0]
+    if dist is not None:
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        seen = torch.full((world,), -1, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(seen, torch.tensor([rank], dtype=torch.int64, device=cdev))
+        ranks_seen = sorted(int(v) for v in seen.tolist())
 
     cfg = syn.CONFIGS[args.config]
     P, W, H = cfg["P"], cfg["W"], cfg["H"]
@@ -431,14 +439,52 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same steps over the REFERENCE's tile lists (GSR_CULL=0: sort keys, point_list, ranges, n_contrib bit for bit as the
+    # reference builds them; the default lists leave out the instances a splat cannot reach) -- reported beside the headline
+    ref_lists_ms = None
+    if _lib.get_variant("CULL", 1) and _lib.get_variant("BIN", 1):
+        _lib.set_variant("CULL", 0)
+        for i in range(min(args.warmup, 4)):
+            step(i)
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        ref_lists_ms = 1e3 * (time.perf_counter() - tr) / args.steps
+        _lib.set_variant("CULL", 1)
+
     # scene initialisation kernel of the path (distCUDA2, once per sub-scene): reported next to the step, not part of it
     from based_on_point_cloud_partitions_amd import distCUDA2
     distCUDA2(xyz.detach())
     torch.cuda.synchronize()
     tk = time.perf_counter()
-    distCUDA2(xyz.detach())
+    for _ in range(5):
+        distCUDA2(xyz.detach())
     torch.cuda.synchronize()
-    knn_ms = round(1e3 * (time.perf_counter() - tk), 3)
+    knn_ms = round(1e3 * (time.perf_counter() - tk) / 5, 3)
+
+    # config 5 (BASELINE.json configs[4]): seamless merge of the partitions + evaluation of the merged scene, once, untimed w.r.t.
+    # the headline.  Every rank crops its partition to its origin box (open sides where it has no neighbour), ONE all-gather
+    # of the padded [maxN, 59] blocks (RCCL over xGMI at N > 1), np.unique-style dedup, then each rank renders its own
+    # partition's camera 0 from the MERGED scene and scores it against the same view of its own un-cropped partition (what
+    # "seamless" means: PSNR across the seams).  Reports what the collective saw, so a multi-GPU run documents itself.
+    from based_on_point_cloud_partitions_amd import evaluate, merge
+    boxes = []
+    for r_ in range(world):
+        bx0, bx1, by0, by1 = syn.partition_origin_box(r_, world)
+        boxes.append((bx0, by0, bx1, by1))
+    with torch.no_grad():
+        raw_block = merge.pack_block(xyz.detach(), shs.detach()[:, :1], shs.detach()[:, 1:],
+                                     torch.logit(opac.detach().clamp(1e-6, 1 - 1e-6)), torch.log(scales.detach()), rots.detach())
+        views = [syn.ring_cameras(cfg["cameras"], W, H, cfg["focal"],
+                                  center=(0.5 * (b[0] + b[2]), 0.5 * (b[1] + b[3]), 0.0) if world > 1 else centre)[0].to(dev)
+                 for b in boxes]
+        gts = [None] * world
+        gts[rank] = evaluate.render_rows(raw_block, views[rank], bg).clamp(0.0, 1.0)
+        ev = evaluate.seamless_merge_and_evaluate(raw_block, rank, boxes if world > 1 else [(None, None, None, None)], views, gts, bg)
+    merged_rows = int(ev["merged"].shape[0])
+    del raw_block, gts
 
     full = None
     if args.full_step:
@@ -500,6 +546,10 @@ def main():
                                 "fraction is low by construction -- see roofline_kernels for the streaming stages and "
                                 "roofline_step for the whole step"}
             roofline["traffic"] = pmc.get(d["kernel"], {}).get("hbm_bytes")
+            # `traffic` (and valu_insts) are NOT measured by this run: they are the PMC passes recorded in the profile file below,
+            # attached only because its workload and kernel-source hash equal this run's
+            roofline["traffic_source"] = (f"profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; build {build}, same workload)"
+                                          if roofline["traffic"] is not None else None)
             for extra in ("valu_insts", "simd_cycles_per_valu_inst"):  # what actually bounds the blend kernels
                 if extra in d:
                     roofline[extra] = d[extra]
@@ -520,7 +570,22 @@ def main():
                                "instances_listed_mean": round(float(np.mean([u["listed"] for u in used])), 1),
                                "per_camera": [{"V": u["V"], "R": u["R"], "tile_list_mean": round(u["tile_mean"], 1),
                                                "tile_list_max": u["tile_max"], "listed": u["listed"]} for u in stats]},
+            "ms_per_step_reference_lists": round(ref_lists_ms, 4) if ref_lists_ms is not None else None,
             "knn_init_ms": knn_ms,
+            "knn_points_per_s": round(P / (knn_ms * 1e-3), 1),
+            "roofline_knn": {"bound": "hbm", "algorithmic_bytes": 120 * P, "achieved": round(120 * P / 1e9 / (knn_ms * 1e-3), 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(120 * P / 1e9 / (knn_ms * 1e-3) / HBM_PEAK_GBS, 4),
+                             "note": "SURVEY.md 8(d): ~120 B per point + data-dependent candidate gathers (L2 / Infinity Cache)"},
+            "rccl_world_size": len(ranks_seen), "rccl_ranks_seen": ranks_seen,
+            "collective_backend": (dist.get_backend() if dist is not None else None),
+            "merge": {"world_size": ev["world_size"], "rows_per_rank_after_crop": ev["counts"], "merged_rows": merged_rows,
+                      "merge_allgather_ms": round(ev["merge_allgather_ms"], 3),
+                      "allgather_bytes_per_rank": int(max(ev["counts"]) * merge.ROW * 4),
+                      "dedup_ms": round(ev["dedup_ms"], 3), "views_scored": ev["views_scored"],
+                      "seam_psnr_db": (round(ev["psnr"], 3) if np.isfinite(ev["psnr"]) else None), "seam_ssim": round(ev["ssim"], 6),
+                      "note": "config 5, once after the timed region: crop -> all_gather_into_tensor of padded [maxN,59] blocks -> "
+                              "first-occurrence lexicographic dedup; each rank scores its partition's camera 0 rendered from the merged "
+                              "scene against its own un-cropped partition (PSNR None = identical images)"},
             "rendered_mpix_per_s_fwd": round(world * N / 1e6 / (fwd_ms * 1e-3), 1) if fwd_ms > 0 else None,
             "roofline": roofline,
             "roofline_step": {"bound": "hbm", "algorithmic_bytes": int(step_bytes),

@@ -315,7 +315,10 @@ uint32_t orc_getHigherMsb(uint32_t n)
 }
 
 /* Stable LSD radix sort of (u64 key, u32 value) on bits [0, end_bit) -- the
- * contract of cub::DeviceRadixSort::SortPairs at rasterizer_impl.cu:303-308. */
+ * contract of cub::DeviceRadixSort::SortPairs at rasterizer_impl.cu:303-308.
+ * OpenMP: the input is cut into one contiguous chunk per thread; per digit pass every thread counts its chunk, the
+ * (digit-major, chunk-minor) exclusive scan of the counts gives every chunk its first slot per digit, and every thread
+ * scatters its chunk in order -- equal digits keep their input order, so each pass (and the whole sort) is stable. */
 static void radix_sort_pairs(long n, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, int end_bit)
 {
     uint64_t* ka = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
@@ -324,24 +327,44 @@ static void radix_sort_pairs(long n, const uint64_t* kin, const uint32_t* vin, u
     uint32_t* vb = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
     memcpy(ka, kin, sizeof(uint64_t) * (size_t)n);
     memcpy(va, vin, sizeof(uint32_t) * (size_t)n);
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+#endif
+    if (n < 65536) nt = 1;
+    size_t* hist = (size_t*)malloc(sizeof(size_t) * 256 * (size_t)nt);
     for (int shift = 0; shift < end_bit; shift += 8) {
         int bits = end_bit - shift < 8 ? end_bit - shift : 8;
         uint32_t mask = (1u << bits) - 1u;
-        size_t hist[257];
-        memset(hist, 0, sizeof(hist));
-        for (long i = 0; i < n; i++) hist[((ka[i] >> shift) & mask) + 1]++;
-        for (int d = 0; d < 256; d++) hist[d + 1] += hist[d];
-        for (long i = 0; i < n; i++) {
-            size_t pos = hist[(ka[i] >> shift) & mask]++;
-            kb[pos] = ka[i];
-            vb[pos] = va[i];
+        memset(hist, 0, sizeof(size_t) * 256 * (size_t)nt);
+#pragma omp parallel num_threads(nt)
+        {
+            int t = 0;
+#ifdef _OPENMP
+            t = omp_get_thread_num();
+#endif
+            const long lo = n * t / nt, hi = n * (t + 1) / nt;
+            size_t* h = hist + 256 * (size_t)t;
+            for (long i = lo; i < hi; i++) h[(ka[i] >> shift) & mask]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                size_t run = 0;
+                for (int d = 0; d < 256; d++)
+                    for (int c = 0; c < nt; c++) { size_t v = hist[256 * (size_t)c + d]; hist[256 * (size_t)c + d] = run; run += v; }
+            }
+            for (long i = lo; i < hi; i++) {
+                size_t pos = h[(ka[i] >> shift) & mask]++;
+                kb[pos] = ka[i];
+                vb[pos] = va[i];
+            }
         }
         uint64_t* tk = ka; ka = kb; kb = tk;
         uint32_t* tv = va; va = vb; vb = tv;
     }
     memcpy(kout, ka, sizeof(uint64_t) * (size_t)n);
     memcpy(vout, va, sizeof(uint32_t) * (size_t)n);
-    free(ka); free(va); free(kb); free(vb);
+    free(hist); free(ka); free(va); free(kb); free(vb);
 }
 
 /* ------------------------------------------------------------------------
@@ -517,7 +540,7 @@ void orc_block_flags(int W, int H, const uint32_t* ranges, const uint32_t* point
  * computes every per-pair term in fp32 exactly as typed and accumulates the sums
  * in double (the order-free ideal of those atomics), rounding once at the end.
  * dL_dmean2D is [P][3] (z untouched = 0), dL_dconic is [P][4] (x,y,w used). */
-void orc_render_backward(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
+static void render_backward_impl(int abs_mode, int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
                          const float* means2D, const float* conic_opacity, const float* colors, const float* final_Ts,
                          const uint32_t* n_contrib, const float* dL_dpixels,
                          /* out */ float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors)
@@ -561,13 +584,36 @@ void orc_render_backward(int P, int W, int H, const uint32_t* ranges, const uint
                         last_color[ch] = c;
                         const float dL_dchannel = dL_dpixel[ch];
                         dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-                        a[6 + ch] += (double)(dchannel_dcolor * dL_dchannel);
+                        a[6 + ch] += (double)(abs_mode ? fabsf(dchannel_dcolor * dL_dchannel) : dchannel_dcolor * dL_dchannel);
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
                     float bg_dot_dpixel = 0;
                     for (int i = 0; i < 3; i++) bg_dot_dpixel += bg[i] * dL_dpixel[i];
                     dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    if (abs_mode) {
+                        /* Condition-number pass (orc_render_backward_abs): every product keeps its factors' magnitudes and
+                         * every sum adds magnitudes, so a[j] bounds the sum of |terms| that ANY summation of this gradient --
+                         * per-pixel gradients as here, or moments of G*dL_dalpha as the HIP kernel forms -- adds up. */
+                        float mag = 0.0f;
+                        for (int ch = 0; ch < 3; ch++) {
+                            /* accum_rec[ch] is already the value this pair sees; last_color[ch] = this pair's colour */
+                            mag += fabsf(last_color[ch] - accum_rec[ch]) * fabsf(dL_dpixel[ch]);
+                        }
+                        mag *= T;
+                        float bgm = 0;
+                        for (int i = 0; i < 3; i++) bgm += fabsf(bg[i] * dL_dpixel[i]);
+                        mag += fabsf(T_final / (1.f - alpha)) * bgm;
+                        const float dLdG = fabsf(con_o[3]) * mag;
+                        const float agdx = fabsf(G * dx), agdy = fabsf(G * dy);
+                        a[0] += (double)(dLdG * (agdx * fabsf(con_o[0]) + agdy * fabsf(con_o[1])) * ddelx_dx);
+                        a[1] += (double)(dLdG * (agdy * fabsf(con_o[2]) + agdx * fabsf(con_o[1])) * ddely_dy);
+                        a[2] += (double)(0.5f * agdx * fabsf(dx) * dLdG);
+                        a[3] += (double)(0.5f * agdx * fabsf(dy) * dLdG);
+                        a[4] += (double)(0.5f * agdy * fabsf(dy) * dLdG);
+                        a[5] += (double)(G * mag);
+                        continue;
+                    }
                     const float dL_dG = con_o[3] * dL_dalpha;
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
@@ -601,6 +647,27 @@ void orc_render_backward(int P, int W, int H, const uint32_t* ranges, const uint
         dL_dcolors[3 * i] = (float)a[6]; dL_dcolors[3 * i + 1] = (float)a[7]; dL_dcolors[3 * i + 2] = (float)a[8];
     }
     free(acc);
+}
+
+void orc_render_backward(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
+                         const float* means2D, const float* conic_opacity, const float* colors, const float* final_Ts,
+                         const uint32_t* n_contrib, const float* dL_dpixels,
+                         /* out */ float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors)
+{
+    render_backward_impl(0, P, W, H, ranges, point_list, bg, means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels,
+                         dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors);
+}
+
+/* The same traversal with every term replaced by its magnitude: out[j] = sum over the blended (pixel, Gaussian) pairs of
+ * |term_j|.  Not a reference function: the tests use it as the computed condition number of each gradient sum
+ * (an fp32 summation of n terms in any order is off by at most ~n_levels * 2^-24 * sum |terms|). */
+void orc_render_backward_abs(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
+                             const float* means2D, const float* conic_opacity, const float* colors, const float* final_Ts,
+                             const uint32_t* n_contrib, const float* dL_dpixels,
+                             /* out */ float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors)
+{
+    render_backward_impl(1, P, W, H, ranges, point_list, bg, means2D, conic_opacity, colors, final_Ts, n_contrib, dL_dpixels,
+                         dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors);
 }
 
 /* auxiliary.h:107-117 */
@@ -815,6 +882,27 @@ void orc_preprocess_backward(int P, int D, int M, const float* means3D, const in
         if (scales)
             computeCov3D_bw(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov3D, dL_dscale, dL_drot);
     }
+}
+
+/* Stand-alone entry points for the pieces of K1 / K10 that the reference's own PYTHON can pin (tests/golden/ref_cov3d.npz,
+ * ref_sh_grad.npz): computeCov3D (forward.cu:118-152) and its backward (backward.cu:278-341) for a batch, and the SH colour
+ * backward (backward.cu:20-139) alone -- dL/dSH and the part of dL/dmean that flows through the view direction. */
+void orc_cov3d(int P, const float* scales, float mod, const float* rots, float* cov3D)
+{
+    for (int i = 0; i < P; i++) computeCov3D(scales + 3 * (size_t)i, mod, rots + 4 * (size_t)i, cov3D + 6 * (size_t)i);
+}
+
+void orc_cov3d_backward(int P, const float* scales, float mod, const float* rots, const float* dL_dcov3D, float* dL_dscales,
+                        float* dL_drots)
+{
+    for (int i = 0; i < P; i++)
+        computeCov3D_bw(i, scales + 3 * (size_t)i, mod, rots + 4 * (size_t)i, dL_dcov3D, dL_dscales, dL_drots);
+}
+
+void orc_sh_backward(int P, int D, int M, const float* means3D, const float* campos, const float* shs, const uint8_t* clamped,
+                     const float* dL_dcolor, float* dL_dmeans, float* dL_dsh)
+{
+    for (int i = 0; i < P; i++) computeColorFromSH_bw(i, D, M, means3D, campos, shs, clamped, dL_dcolor, dL_dmeans, dL_dsh);
 }
 
 /* ------------------------------------------------------------------------

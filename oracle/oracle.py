@@ -172,6 +172,93 @@ def backward(st, dL_dpix):
     return g
 
 
+def backward_condition(st, dL_dpix):
+    """Computed condition numbers of backward(): for every gradient element, an upper bound on the sum of the magnitudes of
+    the terms that any summation order adds up to it.  Blend-level sums (means2D, colours, opacity, conic) come from
+    orc_render_backward_abs; the per-Gaussian chain behind them (K9 + K10) is linear in those eight sums, so its outputs get
+    sum_k |column k of the chain's Jacobian| * S_k, the columns obtained by running the oracle's own chain on one sum at a time.
+    An fp32 accumulation of the blend sums in ANY order then differs from backward() by at most ~c * 2^-24 * this value
+    (c = depth of the summation + rounding of the terms); tests/helpers.py uses it as the only data-dependent tolerance term."""
+    L = lib()
+    P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
+    inp = st["_inputs"]
+    dL_dpix = _f32(dL_dpix).reshape(3, H, W)
+    S = dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
+             dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolors=np.zeros((P, 3), np.float32))
+    cond = dict(S)
+    for k, shape in (("dL_dmeans3D", (P, 3)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)),
+                     ("dL_drotations", (P, 4))):
+        cond[k] = np.zeros(shape, np.float32)
+    if P == 0:
+        return cond
+    colors = inp["colors_precomp"] if inp["colors_precomp"] is not None else st["rgb"]
+    cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else st["cov3D"]
+    L.orc_render_backward_abs(ctypes.c_int(P), ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32),
+                              _p(st["point_list"], _u32), _p(inp["bg"], _f), _p(st["means2D"], _f),
+                              _p(st["conic_opacity"], _f), _p(colors, _f), _p(st["final_T"], _f), _p(st["n_contrib"], _u32),
+                              _p(dL_dpix, _f), _p(S["dL_dmeans2D"], _f), _p(S["dL_dconic"], _f), _p(S["dL_dopacity"], _f),
+                              _p(S["dL_dcolors"], _f))
+    # which outputs a column of the chain's input reaches (the others stay exactly zero and are not touched)
+    reach = dict(dL_dmeans2D=("dL_dmeans3D",), dL_dconic=("dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"),
+                 dL_dcolors=("dL_dmeans3D", "dL_dsh"))
+    out = dict(dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
+               dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
+               dL_drotations=np.zeros((P, 4), np.float32))
+    one = dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
+               dL_dcolors=np.zeros((P, 3), np.float32))
+    for name, col in (("dL_dmeans2D", 0), ("dL_dmeans2D", 1), ("dL_dconic", 0), ("dL_dconic", 1), ("dL_dconic", 3),
+                      ("dL_dcolors", 0), ("dL_dcolors", 1), ("dL_dcolors", 2)):
+        one[name][:, col] = S[name][:, col]
+        for k in reach[name]:
+            out[k].fill(0)
+        L.orc_preprocess_backward(
+            ctypes.c_int(P), ctypes.c_int(D), ctypes.c_int(M), _p(inp["means3D"], _f), _p(st["radii"], _i),
+            _p(inp["shs"] if name == "dL_dcolors" else None, _f), _p(st["clamped"], _u8),
+            _p(inp["scales"] if name == "dL_dconic" else None, _f), _p(inp["rotations"], _f),
+            ctypes.c_float(inp["scale_modifier"]), _p(cov3D, _f), _p(inp["vm"], _f), _p(inp["pm"], _f), ctypes.c_int(W),
+            ctypes.c_int(H), ctypes.c_float(inp["tanfovx"]), ctypes.c_float(inp["tanfovy"]), _p(inp["cp"], _f),
+            _p(one["dL_dmeans2D"], _f), _p(one["dL_dconic"], _f), _p(out["dL_dmeans3D"], _f), _p(one["dL_dcolors"], _f),
+            _p(out["dL_dcov3D"], _f), _p(out["dL_dsh"], _f), _p(out["dL_dscales"], _f), _p(out["dL_drotations"], _f))
+        one[name][:, col] = 0
+        for k in reach[name]:
+            np.abs(out[k], out=out[k])
+            cond[k] += out[k]
+    return cond
+
+
+def cov3d(scales, rotations, scale_modifier=1.0):
+    """computeCov3D (forward.cu:118-152) for a batch: [P,6] upper triangle of R S S^T R^T (the quaternion is used as given)."""
+    L = lib()
+    sc, rot = _f32(scales).reshape(-1, 3), _f32(rotations).reshape(-1, 4)
+    out = np.zeros((sc.shape[0], 6), np.float32)
+    L.orc_cov3d(ctypes.c_int(sc.shape[0]), _p(sc, _f), ctypes.c_float(scale_modifier), _p(rot, _f), _p(out, _f))
+    return out
+
+
+def cov3d_backward(scales, rotations, dL_dcov3D, scale_modifier=1.0):
+    """computeCov3D backward (backward.cu:278-341): (dL_dscales [P,3] w.r.t. scale_modifier * scale, dL_drotations [P,4] w.r.t. the
+    quaternion as given, i.e. without a normalisation in front)."""
+    L = lib()
+    sc, rot, g = _f32(scales).reshape(-1, 3), _f32(rotations).reshape(-1, 4), _f32(dL_dcov3D).reshape(-1, 6)
+    P = sc.shape[0]
+    ds, dr = np.zeros((P, 3), np.float32), np.zeros((P, 4), np.float32)
+    L.orc_cov3d_backward(ctypes.c_int(P), _p(sc, _f), ctypes.c_float(scale_modifier), _p(rot, _f), _p(g, _f), _p(ds, _f), _p(dr, _f))
+    return ds, dr
+
+
+def sh_backward(means3D, campos, shs, clamped, dL_dcolor, sh_degree):
+    """computeColorFromSH backward (backward.cu:20-139) alone: (dL_dsh [P,M,3], the view-direction part of dL_dmeans3D [P,3])."""
+    L = lib()
+    m, sh, g = _f32(means3D).reshape(-1, 3), _f32(shs), _f32(dL_dcolor).reshape(-1, 3)
+    P = m.shape[0]
+    sh = sh.reshape(P, -1, 3)
+    cl = np.ascontiguousarray(np.asarray(clamped, np.uint8).reshape(P, 3))
+    dsh, dm = np.zeros_like(sh), np.zeros((P, 3), np.float32)
+    L.orc_sh_backward(ctypes.c_int(P), ctypes.c_int(sh_degree), ctypes.c_int(sh.shape[1]), _p(m, _f), _p(_f32(campos).reshape(3), _f),
+                      _p(sh, _f), _p(cl, _u8), _p(g, _f), _p(dm, _f), _p(dsh, _f))
+    return dsh, dm
+
+
 def activate(features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw):
     """GaussianModel getters (scene/gaussian_model.py:102-122): returns dict(shs, opacities, scales, rotations)."""
     L = lib()

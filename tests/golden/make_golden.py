@@ -50,6 +50,67 @@ def ref_sh():
     np.savez_compressed(os.path.join(HERE, "ref_sh.npz"), **out)
 
 
+def ref_sh_grad():
+    """Autograd of the reference's own utils/sh_utils.eval_sh through the data flow of gaussian_renderer/__init__.py:73-78
+    (direction = normalised (xyz - campos), colour = clamp_min(eval_sh + 0.5, 0)): d(sum G * rgb)/dSH and /dxyz for a fixed upstream
+    gradient G.  Pins the oracle's computeColorFromSH backward (backward.cu:20-139), clamp mask and dnormvdv included."""
+    sh_utils = _load("ref_sh_utils", "utils/sh_utils.py")
+    g = torch.Generator().manual_seed(321)
+    P = 128
+    xyz0 = 4 * torch.rand(P, 3, generator=g) - 2
+    campos = torch.tensor([1.5, -2.0, 0.7])
+    shs0 = torch.cat((2.0 * torch.randn(P, 1, 3, generator=g), 0.4 * torch.randn(P, 15, 3, generator=g)), 1)  # many clamped channels
+    G = torch.randn(P, 3, generator=g)
+    out = {"xyz": xyz0.numpy(), "campos": campos.numpy(), "shs": shs0.numpy(), "G": G.numpy()}
+    for deg in range(4):
+        xyz = xyz0.clone().double().requires_grad_(True)  # float64: the fixture is the mathematical gradient of the reference's formula
+        shs = shs0.clone().double().requires_grad_(True)
+        shs_view = shs.transpose(1, 2).view(-1, 3, 16)
+        dir_pp = xyz - campos.double().repeat(P, 1)
+        dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        sh2rgb = sh_utils.eval_sh(deg, shs_view[:, :, :(deg + 1) ** 2], dir_pp_normalized)
+        rgb = torch.clamp_min(sh2rgb + 0.5, 0.0)
+        (rgb * G.double()).sum().backward()
+        out[f"clamped_deg{deg}"] = (sh2rgb + 0.5 < 0).numpy()
+        out[f"dsh_deg{deg}"] = shs.grad.numpy()
+        out[f"dxyz_deg{deg}"] = xyz.grad.numpy() if xyz.grad is not None else np.zeros((P, 3))  # degree 0 does not see the direction
+    np.savez_compressed(os.path.join(HERE, "ref_sh_grad.npz"), **out)
+
+
+def ref_cov3d():
+    """The reference's 3D covariance (scene/gaussian_model.py:29-33: L = build_scaling_rotation(mod * s, r); Sigma = L L^T;
+    strip_symmetric) evaluated with its own utils/general_utils.py, and its autograd w.r.t. scale and rotation.  Those helpers
+    hard-code device="cuda" in torch.zeros; the literal is neutralised for this script only.  build_rotation normalises the
+    quaternion, computeCov3D (forward.cu:118-152) takes it as given: the fixture uses unit quaternions, and the rotation gradient
+    the reference's autograd yields is the tangential part (I - q q^T) g of the gradient w.r.t. the quaternion as given."""
+    real_zeros = torch.zeros
+    torch.zeros = lambda *a, **k: real_zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        gu = _load("ref_general_utils", "utils/general_utils.py")
+        g = torch.Generator().manual_seed(99)
+        P = 96
+        scale0 = torch.exp(torch.log(torch.tensor(0.004)) + (torch.log(torch.tensor(0.4)) - torch.log(torch.tensor(0.004))) * torch.rand(P, 3, generator=g))
+        q = torch.randn(P, 4, generator=g)
+        rot0 = (q / q.norm(dim=1, keepdim=True)).double()
+        rot0 = (rot0 / rot0.norm(dim=1, keepdim=True)).float()  # unit to fp32 rounding
+        G = torch.randn(P, 6, generator=g)
+        out = {"scales": scale0.numpy(), "rotations": rot0.numpy(), "G": G.numpy()}
+        for k, mod in enumerate((1.0, 0.6)):
+            s = scale0.clone().double().requires_grad_(True)
+            r = rot0.clone().double().requires_grad_(True)
+            L = gu.build_scaling_rotation(mod * s, r)           # gaussian_model.py:30
+            actual_covariance = L @ L.transpose(1, 2)           # :31
+            symm = gu.strip_symmetric(actual_covariance)        # :32
+            (symm * G.double()).sum().backward()
+            out[f"mod{k}"] = np.array(mod)
+            out[f"cov{k}"] = symm.detach().numpy()
+            out[f"dscale{k}"] = s.grad.numpy()
+            out[f"drot{k}"] = r.grad.numpy()
+        np.savez_compressed(os.path.join(HERE, "ref_cov3d.npz"), **out)
+    finally:
+        torch.zeros = real_zeros
+
+
 def ref_cameras():
     gu = _load("ref_graphics_utils", "utils/graphics_utils.py")
     from based_on_point_cloud_partitions_amd import synthetic as syn
@@ -218,6 +279,8 @@ def oracle_snapshot():
 
 if __name__ == "__main__":
     ref_sh()
+    ref_sh_grad()
+    ref_cov3d()
     ref_cameras()
     ref_loss()
     ref_loss_decoupled()

@@ -174,18 +174,63 @@ def _assert_culled_lists(ex, st):
     assert kept_total == int(got_rg[:, 1].max(initial=0))  # the culled ranges are contiguous: they end at the number of kept entries
 
 
-GRAD_TOL = 1e-4  # BASELINE.json: "within 1e-4 abs on rendered RGB/grad"; applied relative to each tensor's scale
+# Gradient bar (BASELINE.json north_star: "within 1e-4 abs on rendered RGB/grad"), ELEMENT-WISE against the oracle, whose blend sums
+# are accumulated in double:   |got - want| <= GRAD_ATOL + GRAD_RTOL * |want| + GRAD_COND * cond
+# `cond` is the computed condition number of that very element (oracle.backward_condition): the sum of the magnitudes of the terms
+# any summation order adds up to it, pushed through the magnitudes of the per-Gaussian chain's Jacobian.  The HIP kernels sum in
+# fp32 (a 64-lane tree, 4 waves, then a Gaussian's tiles in order) over terms whose factors carry the hardware v_exp / v_rcp
+# (<= 1e-6 relative): their result may differ from a double sum by ~2e-6 * sum|terms| whatever the order, so 4e-6 * cond is the
+# only data-dependent slack, and it exceeds the first two terms only where a gradient is the small remainder of large
+# cancelling contributions.  No per-tensor scale, no blanket exception.
+GRAD_ATOL = 1e-4
+GRAD_RTOL = 1e-4
+GRAD_COND = 4e-6
+GRAD_TOL = GRAD_ATOL
 
 
-def assert_grads_close(got, want, tol=GRAD_TOL):
-    """|got - want| <= tol * max(1, max|want|) element-wise, per gradient tensor."""
+def assert_grads_close(got, want, cond, atol=GRAD_ATOL, rtol=GRAD_RTOL, ccoef=GRAD_COND):
+    """Element-wise bar above.  `cond`: dict with the same keys (oracle.backward_condition / raw_condition).
+    Returns {tensor: worst |err| / tolerance}."""
     worst = {}
     for k in got:
         a, b = got[k].astype(np.float64).reshape(-1), want[k].astype(np.float64).reshape(-1)
         if a.size == 0:
             continue
-        scale = max(1.0, float(np.abs(b).max()))
-        err = float(np.abs(a - b).max())
-        worst[k] = err / scale
-        assert err <= tol * scale, f"{k}: max abs err {err:.3e} vs scale {scale:.3e}"
+        c = np.asarray(cond[k], np.float64).reshape(-1)
+        assert a.shape == b.shape == c.shape, (k, a.shape, b.shape, c.shape)
+        assert np.array_equal(np.isfinite(a), np.isfinite(b)), f"{k}: non-finite values differ"
+        fin = np.isfinite(b)
+        err = np.abs(a[fin] - b[fin])
+        tol = atol + rtol * np.abs(b[fin]) + ccoef * c[fin]
+        ratio = err / tol
+        i = int(np.argmax(ratio)) if ratio.size else 0
+        worst[k] = float(ratio[i]) if ratio.size else 0.0
+        assert worst[k] <= 1.0, (f"{k}: {int((ratio > 1).sum())} of {ratio.size} elements outside the bar; worst |err| {err[i]:.3e} vs "
+                                 f"tolerance {tol[i]:.3e} (want {b[fin][i]:.3e}, cond {c[fin][i]:.3e})")
     return worst
+
+
+def check_backward(ctx, st, dL, keys=None):
+    """HIP backward vs oracle backward for one forward state, at the element-wise bar."""
+    from oracle import oracle
+
+    got, want, cond = hip_backward_raw(ctx, dL), oracle.backward(st, dL), oracle.backward_condition(st, dL)
+    if keys is not None:
+        got = {k: got[k] for k in keys}
+    return assert_grads_close(got, want, cond)
+
+
+def raw_condition(raw_opacity, raw_scaling, raw_rotation, cond):
+    """Condition numbers of the raw-parameter gradients (gsr_backward_params) from those of the activated ones: the chain rule of
+    scene/gaussian_model.py:102-122 with every factor's magnitude -- sigmoid' = o (1 - o), exp' = s, and for
+    normalize: |(g - q (q.g)) / n| <= (c + |q| sum(|q| c)) / n."""
+    o = 1.0 / (1.0 + np.exp(-np.asarray(raw_opacity, np.float64).reshape(-1, 1)))
+    s = np.exp(np.asarray(raw_scaling, np.float64))
+    r = np.asarray(raw_rotation, np.float64)
+    n = np.maximum(np.sqrt((r * r).sum(1, keepdims=True)), 1e-12)
+    q = np.abs(r / n)
+    c = np.asarray(cond["dL_drotations"], np.float64)
+    return dict(dL_dmeans2D=cond["dL_dmeans2D"], dL_dxyz=cond["dL_dmeans3D"], dL_dfeatures_dc=cond["dL_dsh"][:, :1],
+                dL_dfeatures_rest=cond["dL_dsh"][:, 1:], dL_dopacity_raw=np.asarray(cond["dL_dopacity"], np.float64) * o * (1 - o),
+                dL_dscaling_raw=np.asarray(cond["dL_dscales"], np.float64) * s,
+                dL_drotation_raw=(c + q * (q * c).sum(1, keepdims=True)) / n)

@@ -2,8 +2,8 @@
 
 Bars (BASELINE.json north_star / BASELINE.md §5): bit-exact radii, tiles_touched, depth bits, sort keys,
 point_list, ranges, n_contrib -- and, because oracle and kernels share one arithmetic contract, also bit-exact
-final_T and out_color; gradients within 1e-4 (relative to each tensor's scale; the reference itself sums them with
-order-dependent float atomics).
+final_T and out_color; gradients element-wise within 1e-4 + 1e-4 |want| + 4e-6 x the element's computed condition number
+(tests/helpers.py; the reference itself sums them with order-dependent float atomics).
 """
 import os
 
@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (assert_forward_bit_exact, assert_grads_close, hip_backward_raw, hip_forward_raw, hip_settings,
+from helpers import (assert_forward_bit_exact, assert_grads_close, check_backward, hip_backward_raw, hip_forward_raw, hip_settings,
                      oracle_forward, scene)
 from oracle import oracle
 
@@ -52,14 +52,13 @@ def _fwd_bwd(P, W, H, focal, seed=0, bg=(0.0, 0.0, 0.0), deg=3, scale_lo=0.004, 
         assert np.array_equal(ex["cov3D"].view(np.uint32)[vis], st["cov3D"].view(np.uint32)[vis])
     if backward:
         dL = rng.standard_normal((3, H, W)).astype(np.float32)
-        want = oracle.backward(st, dL)
-        got = hip_backward_raw(ctx, dL)
-        assert_grads_close(got, want)
+        check_backward(ctx, st, dL)
     return st, ctx
 
 
 def test_snapshot_scene_against_committed_golden():
-    """HIP vs the committed fixture (tests/golden/oracle_snapshot.npz: stored inputs + oracle outputs), oracle not run."""
+    """HIP vs the committed fixture (tests/golden/oracle_snapshot.npz: stored inputs + oracle outputs); the oracle runs only for
+    the condition numbers of the gradient bar."""
     import hashlib
 
     from helpers import snapshot_scene
@@ -87,7 +86,7 @@ def test_snapshot_scene_against_committed_golden():
     assert np.array_equal(ex["final_T"], fx["final_T"])
     dL = np.random.default_rng(9).standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
     got = hip_backward_raw(ctx, dL)
-    assert_grads_close(got, {k: fx["g_" + k] for k in got})
+    assert_grads_close(got, {k: fx["g_" + k] for k in got}, oracle.backward_condition(oracle_forward(g, cam, bg=bg, sh_degree=3), dL))
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
@@ -144,7 +143,7 @@ def test_many_equal_depths_tie_break_by_index():
     keys = st["keys_sorted"]
     assert (keys[1:] == keys[:-1]).mean() > 0.5  # most neighbours in the sorted list are exact ties
     dL = np.random.default_rng(1).standard_normal((3, 128, 128)).astype(np.float32)
-    assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+    check_backward(ctx, st, dL)
 
 
 @pytest.mark.parametrize("distinct,rep,size,lo_len,hi_len", [(40, 20, 64, 17, 511), (120, 24, 96, 512, 2048)])
@@ -164,7 +163,7 @@ def test_equal_depths_overflow_in_short_and_long_lists(distinct, rep, size, lo_l
     ctx = hip_forward_raw(g2, cam)
     assert_forward_bit_exact(ctx, st)
     dL = np.random.default_rng(3).standard_normal((3, size, size)).astype(np.float32)
-    assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+    check_backward(ctx, st, dL)
 
 
 def test_equal_depths_in_mid_length_lists_overflow_to_the_network():
@@ -212,7 +211,7 @@ def test_config4_2M_gaussians_with_densify_prune_stress():
         st = oracle_forward(gg, cam)
         ctx = hip_forward_raw(gg, cam)
         assert_forward_bit_exact(ctx, st)
-        assert_grads_close(hip_backward_raw(ctx, dL.cpu().numpy()), oracle.backward(st, dL.cpu().numpy()))
+        check_backward(ctx, st, dL.cpu().numpy())
         return st["num_rendered"]
 
     R0 = check(cur, cams[0])
@@ -249,6 +248,15 @@ def test_scale_modifier():
 
 def test_mid_scene_100k_vga():
     _fwd_bwd(P=100_000, W=640, H=480, focal=400.0, seed=3, n_cams=8, cam_index=3)
+
+
+@pytest.mark.parametrize("cam_index", range(1, 16))
+def test_config2_500k_1080p_every_camera_of_the_benchmark(cam_index, tile_list_mode):
+    """bench.py times all 16 ring cameras of configs[1]: each of them against the oracle at full size (camera 0: the test below).
+    Forward in both tile-list modes; the backward does not depend on the mode beyond the lists themselves, so the reference-list
+    mode checks it on every fourth camera only (oracle time)."""
+    _fwd_bwd(P=500_000, W=1920, H=1080, focal=1200.0, seed=0, n_cams=16, cam_index=cam_index,
+             backward=(tile_list_mode == "culled" or cam_index % 4 == 0))
 
 
 def test_config2_500k_1080p_full_parity():
@@ -340,6 +348,90 @@ def test_autograd_function_end_to_end():
     vis = rast.markVisible(xyz.detach())
     assert np.array_equal(vis.cpu().numpy(), oracle.mark_visible(ga.xyz.numpy(), cam.world_view_transform.numpy(),
                                                                  cam.full_proj_transform.numpy()))
+
+
+def test_debug_mode_snapshots_and_synchronises(tmp_path, monkeypatch):
+    """raster_settings.debug=True (diff_gaussian_rasterization/__init__.py:83-90,132-139; CHECK_CUDA, auxiliary.h:166-173): results
+    are those of the normal path, and an error of the native call leaves a CPU snapshot of the arguments before it is re-raised."""
+    from based_on_point_cloud_partitions_amd import GaussianRasterizer, GsrError
+    from based_on_point_cloud_partitions_amd import rasterizer as rz
+
+    monkeypatch.chdir(tmp_path)
+    P, W, H = 2000, 96, 80
+    g, cam = scene(P, W, H, 70.0, seed=13, scale_lo=0.01, scale_hi=0.1)
+    dev = "cuda"
+    leaves = lambda: [t.to(dev).clone().requires_grad_(True) for t in (g.xyz, g.opacities, g.shs, g.scales, g.rotations)]
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    out = {}
+    for debug in (False, True):
+        xyz, op, shs, sc, rot = leaves()
+        rast = GaussianRasterizer(hip_settings(cam, (0.0, 0.1, 0.2), 3, device=dev, debug=debug))
+        img, radii = rast(means3D=xyz, means2D=torch.zeros_like(xyz, requires_grad=True), opacities=op, shs=shs, scales=sc, rotations=rot)
+        img.backward(dL)
+        out[debug] = [img.detach(), radii, xyz.grad, op.grad, shs.grad, sc.grad, rot.grad]
+    assert all(torch.equal(a, b) for a, b in zip(out[False], out[True]))
+    assert not (tmp_path / "snapshot_fw.dump").exists() and not (tmp_path / "snapshot_bw.dump").exists()
+
+    # forward: the C ABI rejects 4 SH coefficients for degree 3 (status -2) -> snapshot_fw.dump, exception re-raised
+    xyz, op, shs, sc, rot = leaves()
+    rast = GaussianRasterizer(hip_settings(cam, (0.0, 0.1, 0.2), 3, device=dev, debug=True))
+    with pytest.raises(GsrError, match="SH degree"):
+        rast(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=op, shs=shs[:, :4].contiguous(), scales=sc, rotations=rot)
+    snap = torch.load(tmp_path / "snapshot_fw.dump")
+    assert len(snap) == 19 and all(not t.is_cuda for t in snap if isinstance(t, torch.Tensor))
+    assert torch.equal(snap[1], g.xyz) and snap[14].shape == (P, 4, 3) and snap[15] == 3 and snap[18] is True
+    # without debug the same error surfaces, and nothing is written
+    (tmp_path / "snapshot_fw.dump").unlink()
+    rast_nd = GaussianRasterizer(hip_settings(cam, (0.0, 0.1, 0.2), 3, device=dev, debug=False))
+    with pytest.raises(GsrError, match="SH degree"):
+        rast_nd(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=op, shs=shs[:, :4].contiguous(), scales=sc, rotations=rot)
+    assert not (tmp_path / "snapshot_fw.dump").exists()
+
+    # backward: a num_rendered the binning buffer was not sized for makes the C ABI return -3 -> snapshot_bw.dump
+    real = rz._C.rasterize_gaussians_backward
+
+    def inflated(*args):
+        a = list(args)
+        a[17] = a[17] * 1000 + 1000  # num_rendered
+        return real(*a)
+
+    monkeypatch.setattr(rz._C, "rasterize_gaussians_backward", staticmethod(inflated))
+    img, _ = rast(means3D=xyz, means2D=torch.zeros_like(xyz, requires_grad=True), opacities=op, shs=shs, scales=sc, rotations=rot)
+    with pytest.raises(GsrError, match="too small"):
+        img.backward(dL)
+    snap = torch.load(tmp_path / "snapshot_bw.dump")
+    assert len(snap) == 21 and torch.equal(snap[12], dL.cpu()) and snap[20] is True
+
+
+def test_extreme_needles_clipped_at_the_image_border():
+    """200:1 ... 500:1 needles, far longer than the image, at every orientation: their tile rectangle is the whole 8 x 8-tile image
+    (<= 64 tiles, so the reach mask decides which instances are listed), and the conic is so ill-conditioned (cx cz / det up to
+    ~1e5) that the fp32 cancellation in det and in the blend's own power evaluation exceeds a fixed 1e-3 margin.  The reach tests
+    scale their margins with the conditioning and make no statement beyond kappa = 4096 (common.h, GSR_REACH_REL): culled lists
+    must still contain every entry the oracle blends, and the image stays bit-exact."""
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    P, W, H = 1500, 128, 128
+    g, cam = scene(P, W, H, 200.0, seed=41, scale_lo=0.002, scale_hi=0.004)
+    gen = torch.Generator().manual_seed(11)
+    scales = g.scales.clone()
+    scales[:, 0] = 1.0 + 5.0 * torch.rand(P, generator=gen)   # 1 .. 6 world units: sigma of 40 .. 270 px at depth ~5 -> 3 sigma >> image
+    scales[: P // 3, 0] *= 0.1                                  # a third of them moderately long (kappa below the cut-off)
+    q = torch.randn(P, 4, generator=gen)
+    rots = q / q.norm(dim=1, keepdim=True)
+    op = torch.rand(P, 1, generator=gen)
+    op[::4] = 1.0 / 255.0 + 1e-3 * torch.rand(P, 1, generator=gen)[::4]
+    op[1::9] = 1.0
+    xyz = g.xyz * torch.tensor([0.5, 0.5, 0.5])
+    g = syn.SyntheticGaussians(xyz, scales, rots, op, g.shs)
+    st = oracle_forward(g, cam, bg=(0.3, 0.0, 0.1))
+    co = st["conic_opacity"][st["radii"] > 0].astype(np.float64)
+    kappa = co[:, 0] * co[:, 2] / (co[:, 0] * co[:, 2] - co[:, 1] ** 2)
+    assert (kappa > 4096).sum() > 50 and ((kappa > 100) & (kappa < 4096)).sum() > 50 and (st["tiles_touched"] == 64).sum() > 200
+    ctx = hip_forward_raw(g, cam, bg=(0.3, 0.0, 0.1))
+    assert_forward_bit_exact(ctx, st)
+    dL = np.random.default_rng(6).standard_normal((3, H, W)).astype(np.float32)
+    check_backward(ctx, st, dL)
 
 
 def test_runs_on_a_non_default_stream():
@@ -441,7 +533,7 @@ def test_random_configuration_sweep(seed):
     ctx = hip_forward_raw(g, cam, bg=bg, sh_degree=deg, scale_modifier=mod)
     assert_forward_bit_exact(ctx, st)
     dL = rng.standard_normal((3, H, W)).astype(np.float32)
-    assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+    check_backward(ctx, st, dL)
 
 
 def test_binning_buffer_regrown_after_the_early_head():
@@ -455,7 +547,7 @@ def test_binning_buffer_regrown_after_the_early_head():
         ctx = hip_forward_raw(g, cam)
         assert_forward_bit_exact(ctx, st)
         dL = np.random.default_rng(5).standard_normal((3, H, W)).astype(np.float32)
-        assert_grads_close(hip_backward_raw(ctx, dL), oracle.backward(st, dL))
+        check_backward(ctx, st, dL)
 
 
 def test_thin_diagonal_splats_reach_mask():
@@ -480,11 +572,6 @@ def test_thin_diagonal_splats_reach_mask():
     ctx = hip_forward_raw(g, cam, bg=(0.0, 0.2, 0.4))
     assert_forward_bit_exact(ctx, st)
     dL = np.random.default_rng(5).standard_normal((3, H, W)).astype(np.float32)
-    got, want = hip_backward_raw(ctx, dL), oracle.backward(st, dL)
-    # what the blend backward produces (sums over the pixels of every tile a splat reaches) at the usual bar ...
-    blend = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dsh")
-    assert_grads_close({k: got[k] for k in blend}, {k: want[k] for k in blend})
-    # ... the per-Gaussian chain behind it divides by the determinant of a nearly singular 2D covariance for a 40:1 needle
-    # (backward.cu:197-212): rounding noise of the fp32 sums (2e-6 here; the oracle sums in double) comes out amplified
-    rest = [k for k in got if k not in blend]
-    assert_grads_close({k: got[k] for k in rest}, {k: want[k] for k in rest}, tol=1e-2)
+    # the per-Gaussian chain divides by the determinant of a nearly singular 2D covariance for a 40:1 needle (backward.cu:197-212):
+    # the rounding of the fp32 sums comes out amplified -- by exactly the Jacobian magnitudes the condition numbers carry
+    check_backward(ctx, st, dL)

@@ -63,6 +63,67 @@ def test_merge_two_ranks_matches_numpy_unique(tmp_path):
         assert np.array_equal(got, want)
 
 
+def _worker_eval(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from based_on_point_cloud_partitions_amd import evaluate
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = _blocks()
+    origin = [(-4.0, -1.0, 0.0, 1.0), (0.0, -1.0, 4.0, 1.0)]  # two boxes sharing the edge x = 0
+    res = evaluate.seamless_merge_and_evaluate(torch.from_numpy((a, b)[rank]), rank, origin, [], [], torch.zeros(3))
+    assert res["world_size"] == world and len(res["counts"]) == world and res["views_scored"] == 0
+    np.save(os.path.join(out_dir, f"eval_{rank}.npy"), res["merged"].numpy())
+    np.save(os.path.join(out_dir, f"counts_{rank}.npy"), np.asarray(res["counts"]))
+    dist.destroy_process_group()
+
+
+def test_config5_driver_two_ranks(tmp_path):
+    """evaluate.seamless_merge_and_evaluate (crop by the dynamic boxes -> all_gather_into_tensor -> dedup) over gloo, world 2:
+    both ranks end with the reference's merged scene and report the world size and per-rank counts they saw."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_eval, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = _reference(*_blocks())
+    a, b = _blocks()
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"eval_{r}.npy"), want)
+        assert np.load(tmp_path / f"counts_{r}.npy").tolist() == [int((a[:, 0] <= 0).sum()), int((b[:, 0] >= 0).sum())]
+
+
+def test_dynamic_bounding_box_follows_the_neighbours():
+    """scene/ptgs/merge_partitions.py:10-57: a side is closed only where a partition sharing a boundary SEGMENT has its opposite
+    side on it; corners do not count (shen_partition.py:165-186: the intersection must be a LineString of non-zero length)."""
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    boxes = []
+    for r in range(8):
+        x0, x1, y0, y1 = syn.partition_origin_box(r, 8)
+        boxes.append((x0, y0, x1, y1))
+    assert merge.dynamic_bounding_box(0, boxes) == (None, None, 4.0, 4.0)
+    assert merge.dynamic_bounding_box(1, boxes) == (4.0, None, 12.0, 4.0)
+    assert merge.dynamic_bounding_box(7, boxes) == (20.0, 4.0, None, None)
+    assert merge.dynamic_bounding_box(5, boxes) == (4.0, 4.0, 12.0, None)
+    # a lone partition has no closed side; two boxes touching in a corner only are not neighbours
+    assert merge.dynamic_bounding_box(0, [(0.0, 0.0, 1.0, 1.0)]) == (None, None, None, None)
+    assert merge.dynamic_bounding_box(0, [(0.0, 0.0, 1.0, 1.0), (1.0, 1.0, 2.0, 2.0)]) == (None, None, None, None)
+    # a balanced binary split (density_partition.py): unequal boxes, the big one has two neighbours on its right side
+    split = [(0.0, 0.0, 2.0, 4.0), (2.0, 0.0, 5.0, 1.5), (2.0, 1.5, 5.0, 4.0)]
+    assert merge.dynamic_bounding_box(0, split) == (None, None, 2.0, None)
+    assert merge.dynamic_bounding_box(1, split) == (2.0, None, None, 1.5)
+    assert merge.dynamic_bounding_box(2, split) == (2.0, 1.5, None, None)
+
+
+def test_unpack_block_inverts_pack_block():
+    N = 5
+    xyz, f_dc, f_rest = torch.rand(N, 3), torch.rand(N, 1, 3), torch.rand(N, 15, 3)
+    op, sc, rot = torch.rand(N, 1), torch.rand(N, 3), torch.rand(N, 4)
+    p = merge.unpack_block(merge.pack_block(xyz, f_dc, f_rest, op, sc, rot))
+    for k, v in dict(xyz=xyz, features_dc=f_dc, features_rest=f_rest, opacity=op, scaling=sc, rotation=rot).items():
+        assert torch.equal(p[k], v), k
+
+
 def test_dedup_and_crop_single_process():
     a, b = _blocks()
     rows = torch.from_numpy(np.concatenate([a, b], 0))

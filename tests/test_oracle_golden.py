@@ -48,6 +48,45 @@ def test_sh_to_rgb_matches_reference_eval_sh():
         assert np.array_equal(st["clamped"][vis].astype(bool), (fx[f"rgb_deg{deg}"][vis] == 0) & (st["rgb"][vis] == 0))
 
 
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_backward_matches_autograd_of_reference_eval_sh(deg):
+    """computeColorFromSH backward (backward.cu:20-139) as the oracle restates it vs the float64 autograd of the REFERENCE's own
+    utils/sh_utils.eval_sh through direction normalisation and the clamp (tests/golden/ref_sh_grad.npz): dL/dSH and the
+    view-direction part of dL/dmean."""
+    fx = np.load(os.path.join(G, "ref_sh_grad.npz"))
+    clamped = fx[f"clamped_deg{deg}"]
+    assert clamped.any() and not clamped.all()
+    dsh, dm = oracle.sh_backward(fx["xyz"], fx["campos"], fx["shs"], clamped, fx["G"], deg)
+    want_sh, want_m = fx[f"dsh_deg{deg}"], fx[f"dxyz_deg{deg}"]
+    np.testing.assert_allclose(dsh, want_sh, rtol=2e-6, atol=2e-7)
+    assert np.all(dsh[:, (deg + 1) ** 2:] == 0)  # coefficients above the active degree get no gradient
+    np.testing.assert_allclose(dm, want_m, rtol=0, atol=3e-6 * max(1.0, np.abs(want_m).max()))
+    if deg == 0:
+        assert np.all(dm == 0)
+
+
+def test_cov3d_and_its_backward_match_the_reference_python():
+    """computeCov3D (forward.cu:118-152) and its backward (backward.cu:278-341) vs the reference's own
+    build_scaling_rotation / strip_symmetric (utils/general_utils.py:64-103, combined as scene/gaussian_model.py:29-33) and their
+    float64 autograd (tests/golden/ref_cov3d.npz).  Two reference conventions show: dL_dscales is the gradient w.r.t.
+    scale_modifier * scale (backward.cu:316-319), and the kernel differentiates w.r.t. the quaternion as given while the Python
+    normalises first -- for a unit quaternion the Python gradient is the tangential part (I - q q^T) of the kernel's."""
+    fx = np.load(os.path.join(G, "ref_cov3d.npz"))
+    sc, rot, Gc = fx["scales"], fx["rotations"], fx["G"]
+    assert np.abs(np.linalg.norm(rot.astype(np.float64), axis=1) - 1).max() < 1e-7
+    for k in range(2):
+        mod = float(fx[f"mod{k}"])
+        cov = oracle.cov3d(sc, rot, mod)
+        want = fx[f"cov{k}"]  # off-diagonal entries cancel: fp32 rounding is relative to the Gaussian's largest variance
+        assert np.all(np.abs(cov - want) <= 3e-6 * np.abs(want) + 4e-7 * np.abs(want).max(1, keepdims=True))
+        ds, dr = oracle.cov3d_backward(sc, rot, Gc, mod)
+        want_s, want_r = fx[f"dscale{k}"], fx[f"drot{k}"]
+        np.testing.assert_allclose(ds.astype(np.float64) * mod, want_s, rtol=0, atol=2e-6 * np.abs(want_s).max())
+        q = rot.astype(np.float64)
+        tang = dr - q * (q * dr).sum(1, keepdims=True)
+        np.testing.assert_allclose(tang, want_r, rtol=0, atol=2e-6 * np.abs(want_r).max())
+
+
 def test_camera_matrices_match_reference_graphics_utils():
     fx = np.load(os.path.join(G, "ref_cameras.npz"))
     for k in range(int(fx["n"])):
@@ -195,3 +234,21 @@ def test_knn_origin_is_always_inside_the_morton_box():
     # min/max reductions start from (0,0,0) (simple_knn.cu:191): far-away clouds still give exact results
     pts = (np.random.default_rng(3).uniform(0, 1, (3000, 3)) + 50.0).astype(np.float32)
     assert np.array_equal(oracle.knn_mean_dist2(pts), oracle.knn_mean_dist2(pts, bruteforce=True))
+
+
+def test_backward_condition_bounds_the_gradients():
+    """oracle.backward_condition: sums of |terms| (blend level) pushed through |Jacobian| of the per-Gaussian chain.  It must bound
+    the magnitude of the gradient itself, vanish where the gradient has no terms, and scale linearly with dL/dpixel."""
+    g, cam = scene(1500, 96, 80, 70.0, seed=5, scale_lo=0.01, scale_hi=0.1)
+    st = oracle_forward(g, cam, bg=(0.2, 0.1, 0.0))
+    dL = np.random.default_rng(0).standard_normal((3, 80, 96)).astype(np.float32)
+    want, cond = oracle.backward(st, dL), oracle.backward_condition(st, dL)
+    cond2 = oracle.backward_condition(st, 2 * dL)
+    culled = st["radii"] == 0
+    for k, w in want.items():
+        c = np.asarray(cond[k], np.float64)
+        assert c.shape == w.shape and np.all(c >= 0)
+        assert np.all(np.abs(w) <= c * (1 + 1e-4) + 1e-6 * (1 + c.max())), k
+        assert np.all(c[culled] == 0), k
+        np.testing.assert_allclose(cond2[k], 2 * c, rtol=1e-5, atol=1e-12)
+    assert cond["dL_dmeans2D"].sum() > 5 * np.abs(want["dL_dmeans2D"]).sum()  # N(0,1) dL: the sums cancel heavily

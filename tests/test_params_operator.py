@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GRAD_TOL, assert_forward_bit_exact, assert_grads_close, hip_settings, oracle_forward, scene
+from helpers import GRAD_TOL, assert_forward_bit_exact, assert_grads_close, hip_settings, oracle_forward, raw_condition, scene
 from oracle import oracle
 
 
@@ -119,9 +119,10 @@ def _params_parity(P, W, H, focal, seed=0, deg=3, m=None, bg=(0.0, 0.0, 0.0), sc
     assert np.array_equal(ex["cov3D"].view(np.uint32)[vis], st["cov3D"].view(np.uint32)[vis])
     dL = np.random.default_rng(seed + 100).standard_normal((3, H, W)).astype(np.float32)
     want = oracle.activate_backward(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(), oracle.backward(st, dL))
+    cond = raw_condition(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(), oracle.backward_condition(st, dL))
     got = hip_params_backward(ctx, dL)
     assert got["dL_dfeatures_rest"].shape == want["dL_dfeatures_rest"].shape
-    assert_grads_close(got, want)
+    assert_grads_close(got, want, cond)
     return st, ctx, got
 
 
@@ -155,17 +156,18 @@ def test_params_operator_zero_norm_quaternion_and_empty_model():
     assert_forward_bit_exact(ctx, st)
     dL = np.ones((3, 64, 64), np.float32)
     want = oracle.activate_backward(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(), oracle.backward(st, dL))
+    cond = raw_condition(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(), oracle.backward_condition(st, dL))
     got = hip_params_backward(ctx, dL)
     fin = np.isfinite(want["dL_drotation_raw"]).all(axis=1)
     assert np.array_equal(np.isfinite(got["dL_drotation_raw"]).all(axis=1), fin)
     for k in got:
         if k != "dL_drotation_raw":
-            assert_grads_close({k: got[k]}, {k: want[k]})
+            assert_grads_close({k: got[k]}, {k: want[k]}, cond)
     # gradients of the clamped quaternions are g / 1e-12: compare in relative terms
     a, b = got["dL_drotation_raw"][:50].astype(np.float64), want["dL_drotation_raw"][:50].astype(np.float64)
     ok = np.isfinite(b)
     assert np.all(np.abs(a[ok] - b[ok]) <= 1e-4 * max(1.0, np.abs(b[ok]).max()))
-    assert_grads_close({"r": got["dL_drotation_raw"][50:]}, {"r": want["dL_drotation_raw"][50:]})
+    assert_grads_close({"r": got["dL_drotation_raw"][50:]}, {"r": want["dL_drotation_raw"][50:]}, {"r": cond["dL_drotation_raw"][50:]})
     raw0 = {k: v[:0] for k, v in raw.items()}
     ctx0 = hip_params_forward(raw0, cam, (0.1, 0.2, 0.3), 3)
     assert ctx0["R"] == 0 and torch.all(ctx0["color"] == 0)
