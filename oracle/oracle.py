@@ -162,6 +162,22 @@ def backward(st, dL_dpix):
                           _p(st["conic_opacity"], _f), _p(colors, _f), _p(st["final_T"], _f), _p(st["n_contrib"], _u32),
                           _p(dL_dpix, _f), _p(g["dL_dmeans2D"], _f), _p(g["dL_dconic"], _f), _p(g["dL_dopacity"], _f),
                           _p(g["dL_dcolors"], _f))
+    return chain_backward(st, g)
+
+
+def chain_backward(st, g):
+    """K9 + K10 (the per-Gaussian chain) on given blend sums: g holds dL_dmeans2D [P,3], dL_dconic [P,4], dL_dcolors [P,3]
+    (+ dL_dopacity, passed through); fills and returns the chain's outputs in a copy of g."""
+    L = lib()
+    P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
+    inp = st["_inputs"]
+    g = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in g.items()}
+    g.update(dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
+             dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
+             dL_drotations=np.zeros((P, 4), np.float32))
+    if P == 0:
+        return g
+    cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else st["cov3D"]
     L.orc_preprocess_backward(
         ctypes.c_int(P), ctypes.c_int(D), ctypes.c_int(M), _p(inp["means3D"], _f), _p(st["radii"], _i),
         _p(inp["shs"], _f), _p(st["clamped"], _u8), _p(inp["scales"], _f), _p(inp["rotations"], _f),
@@ -172,57 +188,54 @@ def backward(st, dL_dpix):
     return g
 
 
-def backward_condition(st, dL_dpix):
-    """Computed condition numbers of backward(): for every gradient element, an upper bound on the sum of the magnitudes of
-    the terms that any summation order adds up to it.  Blend-level sums (means2D, colours, opacity, conic) come from
-    orc_render_backward_abs; the per-Gaussian chain behind them (K9 + K10) is linear in those eight sums, so its outputs get
-    sum_k |column k of the chain's Jacobian| * S_k, the columns obtained by running the oracle's own chain on one sum at a time.
-    An fp32 accumulation of the blend sums in ANY order then differs from backward() by at most ~c * 2^-24 * this value
-    (c = depth of the summation + rounding of the terms); tests/helpers.py uses it as the only data-dependent tolerance term."""
+def backward_condition(st, dL_dpix, trials=16, rel=2e-6):
+    """Computed condition numbers of backward(), element by element, for the tests' gradient tolerance.
+    cond[name]: an upper bound on the sum of the magnitudes of the terms that any summation order adds up to the element --
+    blend-level sums (means2D, colours, opacity, conic) from orc_render_backward_abs; for the outputs of the per-Gaussian chain
+    behind them (K9 + K10, linear in those sums) sum_k |column k of its Jacobian| * S_k (orc_chain_condition).
+    cond["noise:" + name] (chain outputs only): max over `trials` random perturbations of the sums within +-rel * S of
+    |chain(perturbed) - chain(sums)| -- the scatter of the chain's own fp32 evaluation over the uncertainty every fp32
+    summation order (the reference's float atomics included) leaves in its inputs.  Where the chain is well behaved this is
+    <= rel * cond (the linear response), and only the EXCESS over that is returned: zero for well-conditioned elements; for
+    nearly singular 2D covariances (needle-shaped splats) the fp32 chain is a step function of its inputs and the scatter is
+    orders of magnitude larger (oracle/gs_oracle.c, orc_chain_condition)."""
     L = lib()
     P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
     inp = st["_inputs"]
     dL_dpix = _f32(dL_dpix).reshape(3, H, W)
-    S = dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
-             dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolors=np.zeros((P, 3), np.float32))
+    mk = lambda: dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
+                      dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolors=np.zeros((P, 3), np.float32))
+    S, x = mk(), mk()
+    shapes = (("dL_dmeans3D", (P, 3)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)), ("dL_drotations", (P, 4)))
     cond = dict(S)
-    for k, shape in (("dL_dmeans3D", (P, 3)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)),
-                     ("dL_drotations", (P, 4))):
-        cond[k] = np.zeros(shape, np.float32)
     if P == 0:
+        for k, shape in shapes:
+            cond[k] = np.zeros(shape, np.float32)
+            cond["noise:" + k] = np.zeros(shape, np.float32)
         return cond
     colors = inp["colors_precomp"] if inp["colors_precomp"] is not None else st["rgb"]
     cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else st["cov3D"]
-    L.orc_render_backward_abs(ctypes.c_int(P), ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32),
-                              _p(st["point_list"], _u32), _p(inp["bg"], _f), _p(st["means2D"], _f),
-                              _p(st["conic_opacity"], _f), _p(colors, _f), _p(st["final_T"], _f), _p(st["n_contrib"], _u32),
-                              _p(dL_dpix, _f), _p(S["dL_dmeans2D"], _f), _p(S["dL_dconic"], _f), _p(S["dL_dopacity"], _f),
-                              _p(S["dL_dcolors"], _f))
-    # which outputs a column of the chain's input reaches (the others stay exactly zero and are not touched)
-    reach = dict(dL_dmeans2D=("dL_dmeans3D",), dL_dconic=("dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"),
-                 dL_dcolors=("dL_dmeans3D", "dL_dsh"))
-    out = dict(dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
-               dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
-               dL_drotations=np.zeros((P, 4), np.float32))
-    one = dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
-               dL_dcolors=np.zeros((P, 3), np.float32))
-    for name, col in (("dL_dmeans2D", 0), ("dL_dmeans2D", 1), ("dL_dconic", 0), ("dL_dconic", 1), ("dL_dconic", 3),
-                      ("dL_dcolors", 0), ("dL_dcolors", 1), ("dL_dcolors", 2)):
-        one[name][:, col] = S[name][:, col]
-        for k in reach[name]:
-            out[k].fill(0)
-        L.orc_preprocess_backward(
-            ctypes.c_int(P), ctypes.c_int(D), ctypes.c_int(M), _p(inp["means3D"], _f), _p(st["radii"], _i),
-            _p(inp["shs"] if name == "dL_dcolors" else None, _f), _p(st["clamped"], _u8),
-            _p(inp["scales"] if name == "dL_dconic" else None, _f), _p(inp["rotations"], _f),
-            ctypes.c_float(inp["scale_modifier"]), _p(cov3D, _f), _p(inp["vm"], _f), _p(inp["pm"], _f), ctypes.c_int(W),
-            ctypes.c_int(H), ctypes.c_float(inp["tanfovx"]), ctypes.c_float(inp["tanfovy"]), _p(inp["cp"], _f),
-            _p(one["dL_dmeans2D"], _f), _p(one["dL_dconic"], _f), _p(out["dL_dmeans3D"], _f), _p(one["dL_dcolors"], _f),
-            _p(out["dL_dcov3D"], _f), _p(out["dL_dsh"], _f), _p(out["dL_dscales"], _f), _p(out["dL_drotations"], _f))
-        one[name][:, col] = 0
-        for k in reach[name]:
-            np.abs(out[k], out=out[k])
-            cond[k] += out[k]
+    for fn, dst in ((L.orc_render_backward_abs, S), (L.orc_render_backward, x)):
+        fn(ctypes.c_int(P), ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32), _p(st["point_list"], _u32), _p(inp["bg"], _f),
+           _p(st["means2D"], _f), _p(st["conic_opacity"], _f), _p(colors, _f), _p(st["final_T"], _f), _p(st["n_contrib"], _u32),
+           _p(dL_dpix, _f), _p(dst["dL_dmeans2D"], _f), _p(dst["dL_dconic"], _f), _p(dst["dL_dopacity"], _f), _p(dst["dL_dcolors"], _f))
+    NO = 16 + 3 * M
+    c = np.zeros((P, NO), np.float32)
+    n = np.zeros((P, NO), np.float32)
+    L.orc_chain_condition(
+        ctypes.c_int(P), ctypes.c_int(D), ctypes.c_int(M), _p(inp["means3D"], _f), _p(st["radii"], _i), _p(inp["shs"], _f),
+        _p(st["clamped"], _u8), _p(inp["scales"], _f), _p(inp["rotations"], _f), ctypes.c_float(inp["scale_modifier"]),
+        _p(cov3D, _f), _p(inp["vm"], _f), _p(inp["pm"], _f), ctypes.c_int(W), ctypes.c_int(H), ctypes.c_float(inp["tanfovx"]),
+        ctypes.c_float(inp["tanfovy"]), _p(inp["cp"], _f), _p(x["dL_dmeans2D"], _f), _p(x["dL_dconic"], _f), _p(x["dL_dcolors"], _f),
+        _p(S["dL_dmeans2D"], _f), _p(S["dL_dconic"], _f), _p(S["dL_dcolors"], _f), ctypes.c_int(trials), ctypes.c_float(rel), _p(c, _f), _p(n, _f))
+    o = 0
+    for k, shape in (("dL_dmeans3D", (P, 3)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)),
+                     ("dL_drotations", (P, 4))):
+        w = int(np.prod(shape[1:]))
+        cond[k] = np.ascontiguousarray(c[:, o:o + w]).reshape(shape)
+        # only what exceeds the linear response rel * cond (already covered by the cond term of the tolerance) is reported
+        cond["noise:" + k] = np.maximum(np.ascontiguousarray(n[:, o:o + w]).reshape(shape) - np.float32(rel) * cond[k], 0)
+        o += w
     return cond
 
 

@@ -252,3 +252,33 @@ def test_backward_condition_bounds_the_gradients():
         assert np.all(c[culled] == 0), k
         np.testing.assert_allclose(cond2[k], 2 * c, rtol=1e-5, atol=1e-12)
     assert cond["dL_dmeans2D"].sum() > 5 * np.abs(want["dL_dmeans2D"]).sum()  # N(0,1) dL: the sums cancel heavily
+
+
+def test_gradient_bar_covers_a_simulated_fp32_summation_on_needles():
+    """Self-consistency of the tests' gradient tolerance (tests/helpers.py) where it matters: 40:1 needles, whose per-Gaussian
+    chain is a step function of its inputs in fp32.  The oracle's chain is fed the oracle's own sums disturbed by 1e-6 * sum|terms|
+    (what an fp32 summation in another order would deliver): every output must stay within the bar, while the bar without its
+    computed terms (1e-4 + 1e-4 |want| alone) would reject a fifth of the chain's outputs."""
+    from helpers import GRAD_ATOL, GRAD_RTOL, assert_grads_close
+
+    P, W, H = 1500, 160, 120
+    g, cam = scene(P, W, H, 150.0, seed=31, scale_lo=0.01, scale_hi=0.02)
+    gen = torch.Generator().manual_seed(7)
+    scales = g.scales.clone()
+    scales[:, 0] *= 40.0 * torch.rand(P, generator=gen) + 1.0
+    scales[:, 2] *= 0.2
+    q = torch.randn(P, 4, generator=gen)
+    g = syn.SyntheticGaussians(g.xyz, scales, q / q.norm(dim=1, keepdim=True), torch.rand(P, 1, generator=gen), g.shs)
+    st = oracle_forward(g, cam, bg=(0.0, 0.2, 0.4))
+    dL = np.random.default_rng(5).standard_normal((3, H, W)).astype(np.float32)
+    want, cond = oracle.backward(st, dL), oracle.backward_condition(st, dL)
+    rng = np.random.default_rng(1)
+    sums = {k: (want[k].astype(np.float64) + 1e-6 * cond[k].astype(np.float64) * rng.uniform(-1, 1, want[k].shape)).astype(np.float32)
+            for k in ("dL_dmeans2D", "dL_dconic", "dL_dcolors", "dL_dopacity")}
+    got = oracle.chain_backward(st, sums)
+    keys = ("dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dmeans2D", "dL_dcolors", "dL_dopacity")
+    worst = assert_grads_close({k: got[k] for k in keys}, want, cond)
+    assert max(worst.values()) > 0.05  # the bar is not vacuous: the disturbed sums use a visible share of it
+    plain = np.mean([np.mean(np.abs(got[k].astype(np.float64) - want[k]) > GRAD_ATOL + GRAD_RTOL * np.abs(want[k]))
+                     for k in ("dL_dcov3D", "dL_dscales", "dL_drotations")])
+    assert plain > 0.05

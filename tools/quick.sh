@@ -3,7 +3,7 @@
 tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
-timeout -k 10 600 python -m pytest tests/test_block_lists.py tests/test_gpu_parity.py -m gpu -x -q > $out/pytest.log 2>&1; tail -3 $out/pytest.log
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $out/pytest.log 2>&1; tail -3 $out/pytest.log
 env "$@" python bench.py --steps 32 --warmup 8 --no-cpu-baseline > $out/bench.log 2>&1
 python3 - <<PY
 import json
