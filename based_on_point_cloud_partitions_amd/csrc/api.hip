@@ -487,7 +487,8 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
         StageTimer t(GSR_STAGE_RENDER_BWD, s);
         gsr_launch_render_backward(W, H, (const uint32_t*)(im + I.ranges), point_list, (const float*)(g + G.splat), background,
                                    (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
-                                   gsr_variant("BIN", 1) ? (const uint32_t*)(b + B.order) : nullptr, (float*)scratch, s);
+                                   gsr_variant("BIN", 1) ? (const uint32_t*)(b + B.order) : nullptr, (float*)scratch,
+                                   (float)R / (float)(gx * gy), s);
     }
     a.cov3D_in = cov3D_precomp ? cov3D_precomp : (const float*)(g + G.cov3D);
     a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);

@@ -193,7 +193,7 @@ void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint3
                                hipStream_t s);
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                                const uint32_t* order, float* grad_rows, hipStream_t s);
+                                const uint32_t* order, float* grad_rows, float mean_list, hipStream_t s);
 int gsr_variant(const char* name, int dflt);  // experiment switch read from the environment (GSR_<name>)
 bool gsr_cull_enabled();                      // tile lists without the instances the splat's alpha >= 1/255 ellipse cannot reach
 struct GaussBackwardArgs {

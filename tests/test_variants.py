@@ -9,21 +9,22 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = dict(QUAD=1, CULL=1, BIN=2, LPT=1, MAILBOX=1, BWD_RS=1, BWD_FASTEXP=1, BWD_BATCH=128, KEYS=0, WAVE8X8=1, EARLY=1, BANDS=8,
+DEFAULTS = dict(QUAD=1, CULL=1, BIN=2, LPT=1, MAILBOX=1, BWD_FASTEXP=1, BWD_NQ=0, KEYS=0, WAVE8X8=1, EARLY=1, BANDS=8,
                 GB_BLOCK=128, PRE_DIRECT=1, GB_DIRECT=1, GB_RK=1)
 ALTERNATIVES = [
-    dict(QUAD=0),                 # every wave walks the whole tile list
+    dict(QUAD=0),                 # forward: every wave walks the whole tile list
     dict(QUAD=0, CULL=0),         # ... over the reference's lists
     dict(BIN=1),                  # whole-image slices instead of bands (culled lists)
     dict(BIN=0),                  # 64-bit radix sort as the reference (reference lists by construction)
     dict(LPT=0),                  # row-major tile launch
     dict(MAILBOX=0),              # num_rendered through memcpy + stream sync
     dict(EARLY=0),                # no early launch of the binning head
-    dict(BWD_RS=0),               # butterfly wave reduction in the backward
     dict(BWD_FASTEXP=0),          # gs_expf in the backward
-    dict(BWD_BATCH=64), dict(BWD_BATCH=256),
+    dict(BWD_NQ=1),               # backward: four waves per tile (one quadrant each)
+    dict(BWD_NQ=2),               # backward: two waves per tile (a 16x8 half each)
+    dict(BWD_NQ=1, BWD_FASTEXP=0), dict(BWD_NQ=2, CULL=0),
     dict(KEYS=1),                 # sorted keys written during the forward
-    dict(WAVE8X8=0),              # 16x4 pixel strips per wave
+    dict(WAVE8X8=0),              # forward: 16x4 pixel strips per wave
     dict(BANDS=16),
     dict(GB_BLOCK=256),
     dict(PRE_DIRECT=0),           # SH rows through the LDS tile in preprocess
