@@ -282,3 +282,32 @@ def test_gradient_bar_covers_a_simulated_fp32_summation_on_needles():
     plain = np.mean([np.mean(np.abs(got[k].astype(np.float64) - want[k]) > GRAD_ATOL + GRAD_RTOL * np.abs(want[k]))
                      for k in ("dL_dcov3D", "dL_dscales", "dL_drotations")])
     assert plain > 0.05
+
+
+def test_mean_projection_and_its_backward_match_reference_geom_transform_points():
+    """forward.cu:196-199 (transformPoint4x4 + 1 / (w + 1e-7)) -> ndc2Pix, and the mean-projection part of the preprocess backward
+    (backward.cu:346-396), vs the reference's own utils/graphics_utils.geom_transform_points and its float64 autograd
+    (tests/golden/ref_projection.npz).  The oracle's screen-space gradient dL_dmean2D is w.r.t. the NDC coordinates (the 0.5 W / 0.5 H of
+    ndc2Pix are applied inside the blend backward, backward.cu:460-461), which is what the fixture differentiates."""
+    fx = np.load(os.path.join(G, "ref_projection.npz"))
+    W, H, focal, cx, cy, cz = fx["cam"]
+    cam = syn.make_camera(int(W), int(H), float(focal), (cx, cy, cz))
+    P = fx["xyz"].shape[0]
+    g = syn.SyntheticGaussians(torch.tensor(fx["xyz"]), torch.full((P, 3), 0.02), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1),
+                               torch.full((P, 1), 0.5), torch.zeros(P, 16, 3))
+    st = oracle_forward(g, cam, sh_degree=0)
+    vis = st["radii"] > 0
+    assert vis.sum() > 100 and np.all(fx["view_z"][vis] > 0.2)  # in front of the near plane (auxiliary.h:139-164)
+    np.testing.assert_allclose(st["depths"][vis], fx["view_z"][vis], rtol=2e-6, atol=0)  # p_view.z = the sort key (forward.cu:186-193, :240)
+    # ndc2Pix (auxiliary.h:41-44) of the reference's NDC coordinates
+    want_px = ((fx["ndc"][:, 0] + 1.0) * W - 1.0) * 0.5
+    want_py = ((fx["ndc"][:, 1] + 1.0) * H - 1.0) * 0.5
+    np.testing.assert_allclose(st["means2D"][vis, 0], want_px[vis], rtol=0, atol=2e-4)  # fp32 at up to 640 px
+    np.testing.assert_allclose(st["means2D"][vis, 1], want_py[vis], rtol=0, atol=2e-4)
+    # backward: only the screen-space gradient is non-zero, so dL_dmeans3D is the projection's Jacobian^T applied to it
+    sums = dict(dL_dmeans2D=np.concatenate([fx["G"], np.zeros((P, 1), np.float32)], 1).astype(np.float32),
+                dL_dconic=np.zeros((P, 4), np.float32), dL_dcolors=np.zeros((P, 3), np.float32), dL_dopacity=np.zeros((P, 1), np.float32))
+    got = oracle.chain_backward(st, sums)["dL_dmeans3D"]
+    want = fx["dxyz"]
+    assert np.all(got[~vis] == 0)
+    np.testing.assert_allclose(got[vis], want[vis], rtol=2e-5, atol=2e-6 * np.abs(want[vis]).max())
