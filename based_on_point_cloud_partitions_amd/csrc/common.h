@@ -254,7 +254,7 @@ int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t sc
 
 // ---- device helpers ----
 #ifdef __HIPCC__
-// The blend's exp(): same fully specified algorithm as the oracle's gs_expf (independently written).
+// exp() of the parameter activations: same fully specified algorithm as the oracle's gs_expf (independently written).
 __device__ __forceinline__ float gsr_expf(float x)
 {
     // branch-free form of: if (x < -80) return 0; if (x > 80) x = 80; ...
@@ -273,21 +273,23 @@ __device__ __forceinline__ float gsr_expf(float x)
     return x < -80.0f ? 0.0f : e;
 }
 
-// gsr_expf for arguments known to lie in [-80, 80] (the blend kernels: pthr >= -80 is enforced when a list entry is staged and
-// power <= 0 is tested before): the range handling of gsr_expf is dead there, the value is bit-identical.
-__device__ __forceinline__ float gsr_expf_inrange(float x)
+// The blend's exp(): the same fully specified algorithm as the oracle's gs_expf_blend (independently written), for arguments in
+// [-80, 0] (pthr >= -80 is enforced when a list entry is staged and power <= 0 is tested before): nine instructions, seven of them
+// full-rate fma -- the magic-number add rounds x * log2e to an integer inside an fma, the same fma without the integer gives the
+// fraction exactly, a degree-5 Horner gives 2^f, and the integer goes into the exponent with one shift-add.
+__device__ __forceinline__ float gsr_expf_blend(float x)
 {
-    const float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693359375f, x);
-    r = __builtin_fmaf(n, 2.12194440e-4f, r);
-    float p = 1.9875691500E-4f;
-    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
-    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
-    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
-    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
-    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
-    const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
-    return __int_as_float(__float_as_int(y) + (int)n * (1 << 23));
+    const float L = 1.44269504088896341f, MAGIC = 12582912.0f;
+    const float m = __builtin_fmaf(x, L, MAGIC);
+    const float nf = m - MAGIC;
+    const float f = __builtin_fmaf(x, L, -nf);
+    float p = 0x1.5cbc2cp-10f;
+    p = __builtin_fmaf(p, f, 0x1.3cea8ap-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6b48ep-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebf9bcp-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e42cp-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(m) << 23));
 }
 // Wave-uniform "any lane" test.  __ballot() != 0 compiles to v_cndmask + v_cmp_ne on top of the compare that produced the
 // predicate (two half-rate VALU instructions); the ballot intrinsic folds into a scalar test of the compare's own lane mask.

@@ -97,9 +97,9 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
 
 constexpr int NV = 9;  // partial sums per list entry
 
-// FAST_EXP: G = exp(power) from the hardware exp2 (v_exp_f32, <= 1e-6 relative off gsr_expf on the range that can pass), 2 issue slots
-// instead of the 17 instructions of the forward's fully specified gsr_expf.  The alpha >= 1/255 decision must be the forward's: when
-// any lane's alpha lies within 3e-8 of the threshold the wave redoes the entry with gsr_expf, so the blended set is exactly the forward's.
+// FAST_EXP: G = exp(power) from the hardware exp2 (v_exp_f32, <= 1e-6 relative off gsr_expf_blend on the range that can pass), 2 issue slots
+// instead of the 9 instructions of the forward's fully specified gsr_expf_blend.  The alpha >= 1/255 decision must be the forward's: when
+// any lane's alpha lies within 3e-8 of the threshold the wave redoes the entry with gsr_expf_blend, so the blended set is exactly the forward's.
 template <int NQ, bool FAST_EXP>
 __global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 6 : 7)))
 render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ranges,
@@ -268,11 +268,11 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     const unsigned long long m_maybe = act[q] & __builtin_amdgcn_ballot_w64(power >= b.z);  // power > 0: below
                     if (m_maybe == 0ull) continue;
                     unsigned long long m_c = m_maybe & __builtin_amdgcn_ballot_w64(power <= 0.0f);
-                    float G = FAST_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gsr_expf_inrange(power);
+                    float G = FAST_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gsr_expf_blend(power);
                     float alpha = fminf(0.99f, b.y * G);
                     if (FAST_EXP && (m_c & __builtin_amdgcn_ballot_w64(fabsf(alpha - 1.0f / 255.0f) < 3e-8f)) != 0ull) {
                         asm volatile("" ::: "memory");  // a real (rarely taken) branch: keeps the compiler from speculating the 15 instructions
-                        G = gsr_expf_inrange(power);
+                        G = gsr_expf_blend(power);
                         alpha = fminf(0.99f, b.y * G);
                     }
                     m_c &= __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);

@@ -7,7 +7,7 @@
 // stops when all four have (the reference's __syncthreads_count early exit, forward.cu:301-304).
 //
 // Arithmetic contract with the CPU oracle: power / colour accumulation use the explicit fmaf pairs
-// below ("CONTRACT-FMA"), exp is gsr_expf -> final_T, n_contrib and out_color are bit-identical.
+// below ("CONTRACT-FMA"), exp is gsr_expf_blend -> final_T, n_contrib and out_color are bit-identical.
 // The `pthr` test is a pure shortcut: power < ln(1/(255*opacity)) - 1e-3 implies alpha < 1/255 for any
 // exp accurate to 1e-6, so skipping the exp there cannot change a decision.
 #include "common.h"
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                     const bool maybe = power >= b.z;
                     if (gsr_any(maybe)) {  // wave-uniform
                         if (maybe && px != PARKED && power <= 0.0f) {
-                            const float alpha = fminf(0.99f, b.y * gsr_expf_inrange(power));
+                            const float alpha = fminf(0.99f, b.y * gsr_expf_blend(power));
                             if (alpha >= 1.0f / 255.0f) {
                                 const float test_T = T * (1.0f - alpha);
                                 if (test_T < 0.0001f) {
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                     const bool maybe = power >= b.z;
                     if (gsr_any(maybe)) {  // wave-uniform; rare relative to the skip
                         if (maybe && px != PARKED && power <= 0.0f) {
-                            const float alpha = fminf(0.99f, b.y * gsr_expf_inrange(power));
+                            const float alpha = fminf(0.99f, b.y * gsr_expf_blend(power));
                             if (alpha >= 1.0f / 255.0f) {
                                 const float test_T = T * (1.0f - alpha);
                                 if (test_T < 0.0001f) {

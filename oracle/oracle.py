@@ -39,8 +39,9 @@ def lib():
             build()
         _LIB = ctypes.CDLL(so)
         _LIB.orc_preprocess.restype = ctypes.c_long
-        _LIB.gs_expf.restype = ctypes.c_float
-        _LIB.gs_expf.argtypes = [ctypes.c_float]
+        for fn in (_LIB.gs_expf, _LIB.gs_expf_blend):
+            fn.restype = ctypes.c_float
+            fn.argtypes = [ctypes.c_float]
         _LIB.orc_getHigherMsb.restype = ctypes.c_uint32
         _LIB.orc_getHigherMsb.argtypes = [ctypes.c_uint32]
     return _LIB
@@ -60,12 +61,14 @@ def _f32(a):
     return a if a.size else None
 
 
-def gs_expf(x):
+def gs_expf(x, blend=False):
+    """The two fully specified exp functions of the arithmetic contract: gs_expf (activations) or gs_expf_blend (alpha blending)."""
     L = lib()
+    fn = L.gs_expf_blend if blend else L.gs_expf
     x = np.asarray(x, dtype=np.float32)
     out = np.empty_like(x)
     for k, v in enumerate(x.ravel()):
-        out.ravel()[k] = L.gs_expf(ctypes.c_float(float(v)))
+        out.ravel()[k] = fn(ctypes.c_float(float(v)))
     return out
 
 

@@ -25,6 +25,21 @@ def test_gs_expf_accuracy_and_range():
     assert np.all(np.diff(ys) >= 0)
 
 
+def test_gs_expf_blend_accuracy_and_range():
+    """The blend's exp (9 instructions on the GPU: magic-number rounding inside an fma, degree-5 2^f): as accurate as gs_expf on the
+    range the blend can ask for -- alpha >= 1/255 needs power >= ln(1/255) = -5.54 --, monotone, exact at 0, 0 below -80."""
+    x = np.concatenate([np.linspace(-6.0, 0.0, 40001), -np.logspace(-8, 0.7, 2001)]).astype(np.float32)
+    got = oracle.gs_expf(x, blend=True).astype(np.float64)
+    assert np.max(np.abs(got - np.exp(x.astype(np.float64))) / np.exp(x.astype(np.float64))) < 3e-7
+    x = np.linspace(-80.0, 0.0, 40001).astype(np.float32)
+    got = oracle.gs_expf(x, blend=True).astype(np.float64)
+    assert np.max(np.abs(got - np.exp(x.astype(np.float64))) / np.exp(x.astype(np.float64))) < 1.5e-6
+    assert oracle.gs_expf(np.float32(-80.5), blend=True) == 0.0 and oracle.gs_expf(np.float32(0.0), blend=True) == 1.0
+    assert oracle.gs_expf(np.float32(-0.0), blend=True) == 1.0
+    xs = np.linspace(-12, 0, 6001).astype(np.float32)
+    assert np.all(np.diff(oracle.gs_expf(xs, blend=True)) >= 0)
+
+
 def test_higher_msb_matches_reference_bit_counts():
     # rasterizer_impl.cu:300: 1080p -> 13 tile bits (45-bit keys), 256x256 -> 9 (41-bit keys)  (SURVEY.md §2.1 K5)
     L = oracle.lib()
