@@ -277,14 +277,24 @@ def test_config2_500k_1080p_full_parity():
     assert int(ex["tiles_touched"].cpu().numpy().view(np.uint32).astype(np.int64).sum()) == ctx["R"]
 
 
-def test_backward_is_bitwise_reproducible():
+@pytest.mark.parametrize("nq", [1, 2])
+def test_backward_is_bitwise_reproducible(nq):
+    """No float atomics in HBM and a fixed summation order: two runs give the same bits.  Both work splits of the blend backward --
+    with two quadrants per wave the two waves of a tile add into one LDS row with float atomics, but two addends commute."""
+    from based_on_point_cloud_partitions_amd import _lib
+
     g, cam = scene(20_000, 256, 256, 160.0, seed=4, scale_lo=0.01, scale_hi=0.1)
     ctx = hip_forward_raw(g, cam)
     dL = np.random.default_rng(0).standard_normal((3, 256, 256)).astype(np.float32)
-    a = hip_backward_raw(ctx, dL)
-    b = hip_backward_raw(ctx, dL)
-    for k in a:
-        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    _lib.set_variant("BWD_NQ", nq)
+    try:
+        a = hip_backward_raw(ctx, dL)
+        for _ in range(3):
+            b = hip_backward_raw(ctx, dL)
+            for k in a:
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    finally:
+        _lib.set_variant("BWD_NQ", 0)
 
 
 def test_all_culled_and_empty():
