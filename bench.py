@@ -307,6 +307,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="cfg2", choices=sorted(syn.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", default="as-generated", choices=["as-generated", "morton"],
+                    help="memory order of the Gaussians: the workload's own (random, BASELINE.md) or sorted by the Morton code of xyz "
+                         "(what a trainer gets by re-ordering its model at densification time; not the headline workload)")
     ap.add_argument("--no-stage-timers", action="store_true", help="time the region without per-stage HIP events")
     ap.add_argument("--full-step", action="store_true",
                     help="also time the step from raw parameters (activations fused or not) and with the L1/SSIM loss (train.py:107-118)")
@@ -345,6 +348,16 @@ def main():
         centre = (0.0, 0.0, 0.0)
     else:
         g, centre, _box = syn.make_partition(rank, world, P, seed=0)
+    if args.order == "morton":
+        q = ((g.xyz - g.xyz.min(0).values) / (g.xyz.max(0).values - g.xyz.min(0).values + 1e-9) * 1023.0).to(torch.int64)
+
+        def spread(v):  # 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        perm = torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), stable=True)
+        g = syn.SyntheticGaussians(*[t[perm].contiguous() for t in g])
     cams = syn.ring_cameras(cfg["cameras"], W, H, cfg["focal"], center=centre)
     dL_cpu = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
     dL = dL_cpu.to(dev)
@@ -561,7 +574,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "build": build,
-            "config": {"workload": workload, "gaussians_per_gpu": P,
+            "config": {"workload": workload + ("" if args.order == "as-generated" else f" [Gaussians in {args.order} order]"), "gaussians_per_gpu": P,
                        "image": [W, H], "sh_degree": 3, "parallelism": f"{world} independent partition(s), 1 per GPU"},
             "workload_stats": {"P": P, "V_mean": round(V, 1), "R_mean": round(R, 1), "N": N, "key_bits": key_bits,
                                "tile_list_mean": round(float(np.mean([u["tile_mean"] for u in used])), 1),
