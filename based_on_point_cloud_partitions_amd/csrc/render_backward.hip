@@ -383,8 +383,9 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     int nq = gsr_variant("BWD_NQ", 0);
     // two quadrants per wave pay when the lists are short AND the image has enough tiles to fill the chip with half as many waves
-    // (measured, ms: 500k Gaussians 1080p 0.374 vs 0.397; 2M Gaussians 1080p 0.745 vs 0.636; 10k Gaussians 256x256 0.121 vs 0.064)
-    if (nq != 1 && nq != 2) nq = (mean_list < (float)gsr_variant("BWD_NQ_LIST", 900) && gx * gy >= gsr_variant("BWD_NQ_TILES", 4096)) ? 2 : 1;
+    // (measured at 1080p, ms, NQ = 2 vs 1: 500k Gaussians, mean list 467: 0.374 vs 0.397; 1M, 930: 0.461 vs 0.434; 1.5M, 1400: 0.609 vs 0.521;
+    // 2M, 1866: 0.745 vs 0.636; and 10k Gaussians at 256x256, 256 tiles: 0.121 vs 0.064)
+    if (nq != 1 && nq != 2) nq = (mean_list < (float)gsr_variant("BWD_NQ_LIST", 700) && gx * gy >= gsr_variant("BWD_NQ_TILES", 4096)) ? 2 : 1;
     const bool fast = gsr_variant("BWD_FASTEXP", 1) != 0;
 #define GSR_BWD_LAUNCH(NQ_, F_)                                                                                                  \
     hipLaunchKernelGGL((render_backward_kernel<NQ_, F_>), dim3(gx * gy), dim3(64 * (4 / NQ_)), 0, s, W, H, gx, gy, order, ranges, \

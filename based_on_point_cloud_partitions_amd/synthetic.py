@@ -155,6 +155,10 @@ CONFIGS = {
     "cfg1": dict(P=10_000, W=256, H=256, focal=160.0, cameras=4),
     "cfg2": dict(P=500_000, W=1920, H=1080, focal=1200.0, cameras=16),
     "cfg4": dict(P=2_000_000, W=1920, H=1080, focal=1200.0, cameras=16),
+    # not a BASELINE.json configuration: cfg2's box at twice / three times the density (mean reference tile list ~930 / ~1400), used to
+    # place the list-length threshold between the two work splits of the blend backward
+    "dense1m": dict(P=1_000_000, W=1920, H=1080, focal=1200.0, cameras=16),
+    "dense1m5": dict(P=1_500_000, W=1920, H=1080, focal=1200.0, cameras=16),
 }
 
 
