@@ -12,12 +12,15 @@
 //
 // Work split.  A tile is 16x16 pixels = four 8x8 quadrants.  A wave owns NQ quadrants (NQ pixels per lane, state in registers):
 //   NQ = 1: four waves per tile (256 threads).  One wave reduction per (entry, quadrant) that blends: 2.90M on the benchmark scene.
-//   NQ = 2: two waves per tile (128 threads), a 16x8 half each.  The sums of an entry accumulate over the wave's two quadrants in
-//           registers and are reduced once per (entry, half): 1.87M reductions (13 DPP + 15 selects + 2 permlane swaps, a third of
-//           the instructions of a blending instance).  A wave walks twice the pixels, so a tile's critical path is twice as long:
-//           faster where lists are short (500k Gaussians at 1080p: 0.374 vs 0.397 ms), slower where every tile's list is long (2M:
-//           0.745 vs 0.636 ms) or the image has few tiles.  The launcher picks by the mean list length and the tile count.  (NQ = 4, one wave per tile and 1.22M reductions, was
-//           built and measured in round 3: fewest instructions, but the longest tiles alone set the kernel's duration.)
+//   NQ = 2: two waves per tile (128 threads), a 16x8 half each.  A lane's two pixels lie in the same image row, so they share dy: each
+//           blending quadrant leaves (w, w*dx, dx, alpha*T), the two are combined as S w, S w*dx, S w*dx^2, S alpha*T*dL/dpixel, and the y
+//           moments are S w*dy = (S w)*dy, S w*dx*dy = (S w*dx)*dy, S w*dy^2 = (S w*dy)*dy -- 14 instructions for a pair, 8 for a single
+//           quadrant -- and reduced once per (entry, half): 1.87M reductions (13 DPP + 15 selects + 2 permlane swaps, a third of the
+//           instructions of a blending instance).  A wave walks twice the pixels, so a tile's critical path is twice as long: faster
+//           where lists are short (500k Gaussians at 1080p: 0.338 vs 0.375 ms), slower where every tile's list is long (2M: 0.745 vs
+//           0.636 ms) or the image has few tiles.  The launcher picks by the mean list length and the tile count.  (NQ = 4, one wave
+//           per tile and 1.22M reductions, was built and measured in round 3: fewest instructions, but the longest tiles alone set the
+//           kernel's duration.)
 // The quadrants of an entry are visited under SCALAR branches: which staged entries can reach which quadrant (gsr_quad_mask) is a
 // ballot, i.e. a wave-uniform 64-bit mask in SGPRs, and a wave picks its entries with scalar bit scans.
 //
@@ -80,8 +83,10 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "=&v"(t0), "=&v"(t1),
           "=&v"(t2), "=&v"(t3)
         : "s"(m0), "s"(m1), "s"(m2), "s"(m8));
-    // levels 5, 6: lane-wise across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap (two VALU
-    // instructions per level; __shfl_xor would take two dependent trips through the LDS crossbar)
+    // levels 5, 6: lane-wise across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap (two VALU instructions per level).
+    // Measured alternative (round 3): the other three rows fetched with three ds_bpermute_b32 (no VALU issue slot, one LDS round trip) and
+    // added in a fixed order -- 5 fewer VALU instructions per reduction, yet no faster with two waves per tile (0.3473 vs 0.3447 ms) and slower
+    // with four (2M Gaussians 0.676 vs 0.653, 256x256 0.0683 vs 0.0659): the round trip lengthens every entry's dependent chain.
     {
         const uint32_t u = __float_as_uint(v0);
         const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // (row0,row0,row2,row2), (row1,row1,row3,row3)
@@ -178,8 +183,6 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
     const int my_slot = lane < 8 ? (4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1)) : 8;
     float* my_acc = s_acc + (NQ == 2 ? 0 : wave * BATCH * NV);
     const int rounds = (int)((hi + BATCH - 1) / BATCH);
-    // the nine sums of the current entry over the wave's quadrants (zero between entries: cleared after every reduction)
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
 
     for (int i = 0; i < rounds; i++) {
         // ---- stage this batch (back to front): one record per thread; instances whose tile the splat cannot reach own no
@@ -251,22 +254,26 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                 const int j = 64 * w + jj;
                 const float4 a = s_a[j], b = s_b[j], c = s_c[j];
                 const uint32_t kidx = kbase - (uint32_t)j;
-                bool any = false;
-#pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    if (NQ > 1 && !((bq[q] >> jj) & 1ull)) continue;  // scalar: the splat cannot reach this quadrant
+                const float dy = a.y - pyf;  // the wave's quadrants lie side by side: one dy per lane
+                // what a blending quadrant leaves for the sums: w = G * dL/dalpha, dx, alpha * T (NQ = 2: combined below)
+                // (separate scalars, not arrays: an array of two would be kept as a 64-bit register pair and copied into place)
+                float W0, WX0, DX0, AT0, W1, WX1, DX1, AT1;  // defined where bl0 / bl1 say so
+                auto visit = [&](auto Q, float& Wq, float& WXq, float& DXq, float& ATq) -> bool {
+                    constexpr int q = decltype(Q)::value;
+                    if (NQ > 1 && !((bq[q] >> jj) & 1ull)) return false;  // scalar: the splat cannot reach this quadrant
                     // lanes behind whose last contributor this entry lies never see it (backward.cu:480-482).  The walk runs back to
                     // front, so a lane once active stays active: the compare is only needed until every possible lane is
                     if (act[q] != possible[q]) act[q] = __builtin_amdgcn_ballot_w64(kidx < lastc[q]);
-                    if (act[q] == 0ull) continue;
-                    const float dx = a.x - ((NQ > 1 && q) ? pxf1 : pxf0), dy = a.y - pyf;
+                    if (act[q] == 0ull) return false;
+                    float dx;  // a.x - pixel x; as asm so that the result is born in the register it stays in until the sums are formed
+                    asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(a.x), "v"((NQ > 1 && q) ? pxf1 : pxf0));
                     // identical to the forward (CONTRACT-FMA)
                     const float qq = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
                     const float power = __builtin_fmaf(-0.5f, qq, -((a.w * dx) * dy));
                     // Lane predicates are kept as 64-bit lane masks in scalar registers (each ballot of a plain compare IS the
                     // compare's result mask): combining them and testing "any lane" is scalar work
                     const unsigned long long m_maybe = act[q] & __builtin_amdgcn_ballot_w64(power >= b.z);  // power > 0: below
-                    if (m_maybe == 0ull) continue;
+                    if (m_maybe == 0ull) return false;
                     unsigned long long m_c = m_maybe & __builtin_amdgcn_ballot_w64(power <= 0.0f);
                     float G = FAST_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gsr_expf_blend(power);
                     float alpha = fminf(0.99f, b.y * G);
@@ -276,7 +283,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                         alpha = fminf(0.99f, b.y * G);
                     }
                     m_c &= __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
-                    if (m_c == 0ull) continue;
+                    if (m_c == 0ull) return false;
                     // From here all 64 lanes run the same straight-line code.  A lane that does not contribute is given alpha = G = 0:
                     // then T/(1-0) = T, its gradient terms vanish, and the colour recurrence (backward.cu:515) leaves accum unchanged
                     float Ge, ae;
@@ -294,25 +301,42 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     behind[q] = __builtin_fmaf(ae, cdl, oma * behind[q]);
                     dL_dalpha *= T[q];
                     dL_dalpha = __builtin_fmaf(-tfbg[q], inv, dL_dalpha);  // (-T_final / (1 - alpha)) * (bg . dL/dpixel)
-                    const float w_ = Ge * dL_dalpha;
-                    const float aT = ae * T[q];
-                    const float wdx = w_ * dx, wdy = w_ * dy;
-                    if constexpr (NQ == 1) {  // one quadrant per wave: the values go straight into the reduction
-                        const float tot = wave_sum9_scatter(w_, wdx, wdy, wdx * dx, wdx * dy, wdy * dy, aT * dL0[q], aT * dL1[q], aT * dL2[q],
-                                                            M0, M1, M2, M8);
+                    Wq = Ge * dL_dalpha;
+                    WXq = Wq * dx;
+                    DXq = dx;
+                    ATq = ae * T[q];
+                    return true;
+                };
+                const bool bl0 = visit(std::integral_constant<int, 0>{}, W0, WX0, DX0, AT0);
+                const bool bl1 = NQ > 1 ? visit(std::integral_constant<int, NQ - 1>{}, W1, WX1, DX1, AT1) : false;
+                if constexpr (NQ == 1) {  // one quadrant per wave
+                    if (bl0) {
+                        const float wdx = WX0, wdy = W0 * dy;
+                        const float tot = wave_sum9_scatter(W0, wdx, wdy, wdx * DX0, wdx * dy, wdy * dy, AT0 * dL0[0], AT0 * dL1[0],
+                                                            AT0 * dL2[0], M0, M1, M2, M8);
                         if (lane < 9) my_acc[j * NV + my_slot] = tot;
                         wr[w] |= 1ull << jj;
-                    } else {
-                        any = true;
-                        v0 += w_; v1 += wdx; v2 += wdy;
-                        v3 = __builtin_fmaf(wdx, dx, v3); v4 = __builtin_fmaf(wdx, dy, v4); v5 = __builtin_fmaf(wdy, dy, v5);
-                        v6 = __builtin_fmaf(aT, dL0[q], v6); v7 = __builtin_fmaf(aT, dL1[q], v7); v8 = __builtin_fmaf(aT, dL2[q], v8);
                     }
-                }
-                if (NQ > 1 && any) {  // wave-uniform
-                    const float tot = wave_sum9_scatter(v0, v1, v2, v3, v4, v5, v6, v7, v8, M0, M1, M2, M8);
+                } else if (bl0 || bl1) {  // wave-uniform
+                    // the lane's two pixels share dy: the y moments of their sum are products of the x moments with dy
+                    float sw, swx, sxx, c0, c1, c2;
+                    if (bl0 && bl1) {
+                        sw = W0 + W1;
+                        swx = WX0 + WX1;
+                        sxx = __builtin_fmaf(WX1, DX1, WX0 * DX0);
+                        c0 = __builtin_fmaf(AT1, dL0[1], AT0 * dL0[0]);
+                        c1 = __builtin_fmaf(AT1, dL1[1], AT0 * dL1[0]);
+                        c2 = __builtin_fmaf(AT1, dL2[1], AT0 * dL2[0]);
+                    } else if (bl0) {
+                        sw = W0; swx = WX0; sxx = swx * DX0;
+                        c0 = AT0 * dL0[0]; c1 = AT0 * dL1[0]; c2 = AT0 * dL2[0];
+                    } else {
+                        sw = W1; swx = WX1; sxx = swx * DX1;
+                        c0 = AT1 * dL0[1]; c1 = AT1 * dL1[1]; c2 = AT1 * dL2[1];
+                    }
+                    const float swy = sw * dy;
+                    const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M1, M2, M8);
                     if (lane < 9) atomicAdd(&my_acc[j * NV + my_slot], tot);  // LDS
-                    v0 = v1 = v2 = v3 = v4 = v5 = v6 = v7 = v8 = 0.f;
                 }
             }
         }
