@@ -30,63 +30,58 @@
 
 namespace {
 
-// Sums 9 registers over the 64 lanes of a wave by reduce-scatter: after each exchange a lane keeps only half of the values, so 8
-// values cost 12 + 6 + 4 + 1 instructions for the four in-row levels instead of 32 (a butterfly); written as ONE asm block: every
-// DPP read is far enough behind the write it depends on that no wait states are needed inside (hipcc pads nothing in asm), and the
-// compiler cannot re-pack the adds into v_pk_add_f32 + v_mov_dpp pairs (what it emits for the builtin form: 2.5x the instructions).  The 9th value is reduced along its row
-// (4 DPP adds) and parked in lane 8 of each row, and the two cross-row levels are shared by all nine.
-// Result: lane l < 8 holds the wave total of value (4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1)), lane 8 holds the total of v8.
-// m0/m1/m2/m8: lane masks (l&1), (l&2), (l&4), ((l&15)==8).  All 64 lanes must be active.
+// Sums 9 registers over the 64 lanes of a wave by reduce-scatter: at every level a lane adds its partner's copy of the values it keeps
+// and drops the others.  The in-row levels are ordered by what "keep by bit b of the lane" costs in DPP:
+//   lane^4, lane^8 first (eight, then four values): a DPP bank is four CONSECUTIVE lanes, so a bank mask enables lanes by bit 2 or by
+//                  bit 3 and a pair of values is two masked DPP adds -- no select;
+//   lane^1         (two values) bits 0 and 1 cannot be masked: two selects + one DPP add;
+//   lane^2         one value left: plain butterfly.
+// The 9th value is reduced along its row on its own (4 DPP adds slotted between dependent steps) and parked in lane 2, and the two
+// cross-row levels (v_permlane16_swap / v_permlane32_swap, two VALU instructions + a copy each) are shared by all nine.
+// 18 DPP adds + 3 selects; round 2's order (lane^1, ^2, ^4, ^8) needed 13 + 15.  Written as ONE asm block: every DPP read is far enough
+// behind the write it depends on (hipcc pads nothing in asm), and the compiler cannot re-pack the adds into v_pk_add_f32 + v_mov_dpp
+// pairs (what it emits for the builtin form: 2.5x the instructions).
+// Result (lanes 0..15): lane l with bit 1 clear holds the wave total of value (l&1) + 2*((l>>3)&1) + 4*((l>>2)&1), lane 2 that of v8.
+// m0/m2: lane masks (l&1), ((l&15)==2).  All 64 lanes must be active.
+// Measured alternatives (round 3, cfg2 two waves per tile / 2M Gaussians four waves per tile, ms): cross-row levels FIRST with pair-wise
+// permlane swaps (8 swaps + 7 DPP, no select at all): 0.349 / 0.668 against 0.338 / 0.637 -- a swap costs far more than its 8.5 cycles
+// back to back suggest; cross-row levels through ds_bpermute_b32: 0.347 / 0.676 (the LDS round trip lengthens every entry's chain).
 __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
-                                                   float v8, unsigned long long m0, unsigned long long m1,
-                                                   unsigned long long m2, unsigned long long m8)
+                                                   float v8, unsigned long long m0, unsigned long long m2)
 {
-    float t0, t1, t2, t3;
+    float t0;
     asm volatile(
-        // level 1: partner lane^1; lanes with bit0 keep v4..v7, the others v0..v3
-        "v_cndmask_b32 %9, %4, %0, %13\n"   // t = what the partner needs from me
-        "v_cndmask_b32 %10, %5, %1, %13\n"
-        "v_cndmask_b32 %11, %6, %2, %13\n"
-        "v_cndmask_b32 %12, %7, %3, %13\n"
-        "v_cndmask_b32 %0, %0, %4, %13\n"   // v = what I keep
-        "v_cndmask_b32 %1, %1, %5, %13\n"
-        "v_cndmask_b32 %2, %2, %6, %13\n"
-        "v_cndmask_b32 %3, %3, %7, %13\n"
-        "v_add_f32_dpp %0, %9, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %1, %10, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %2, %11, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %3, %12, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        // 9th value, row levels interleaved as independent work between dependent DPP steps
-        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        // level 2: partner lane^2; lanes with bit1 keep slots 2,3
-        "v_cndmask_b32 %9, %2, %0, %14\n"
-        "v_cndmask_b32 %10, %3, %1, %14\n"
-        "v_cndmask_b32 %0, %0, %2, %14\n"
-        "v_cndmask_b32 %1, %1, %3, %14\n"
+        "s_nop 1\n"  // the first DPP reads may follow the instruction that produced their operand (the compiler sees no DPP in here)
+        // lane^4: lanes with bit 2 clear keep v0..v3, the others v4..v7
+        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"  // 9th value
+        // lane^8: lanes 0..7 of a row keep registers 0, 1, lanes 8..15 registers 2, 3
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n"
         "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %0, %9, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %1, %10, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+        "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n"
         "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n"
-        "s_nop 0\n"
-        // level 3: partner lane^4; lanes with bit2 keep slot 1
-        "v_cndmask_b32 %9, %1, %0, %15\n"
-        "v_cndmask_b32 %0, %0, %1, %15\n"
+        // lane^1: lanes with bit 0 keep register 1
+        "v_cndmask_b32 %9, %1, %0, %10\n"   // what the partner needs from me
+        "v_cndmask_b32 %0, %0, %1, %10\n"   // what I keep
         "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n"
-        "s_nop 0\n"
-        "v_add_f32_dpp %0, %9, %0 row_shr:4 row_mask:0xf bank_mask:0xa\n"
-        "v_add_f32_dpp %0, %9, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+        "v_add_f32_dpp %0, %9, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
         "s_nop 1\n"
-        // level 4: partner lane^8
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-        // park the 9th value's row total in lane 8 of each row
-        "v_cndmask_b32 %0, %0, %8, %16\n"
-        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "=&v"(t0), "=&v"(t1),
-          "=&v"(t2), "=&v"(t3)
-        : "s"(m0), "s"(m1), "s"(m2), "s"(m8));
-    // levels 5, 6: lane-wise across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap (two VALU instructions per level).
-    // Measured alternative (round 3): the other three rows fetched with three ds_bpermute_b32 (no VALU issue slot, one LDS round trip) and
-    // added in a fixed order -- 5 fewer VALU instructions per reduction, yet no faster with two waves per tile (0.3473 vs 0.3447 ms) and slower
-    // with four (2M Gaussians 0.676 vs 0.653, 256x256 0.0683 vs 0.0659): the round trip lengthens every entry's dependent chain.
+        // lane^2
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        // park the 9th value's row total in lane 2 of each row
+        "v_cndmask_b32 %0, %0, %8, %11\n"
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "=&v"(t0)
+        : "s"(m0), "s"(m2));
+    // levels 5, 6: lane-wise across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap
     {
         const uint32_t u = __float_as_uint(v0);
         const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // (row0,row0,row2,row2), (row1,row1,row3,row3)
@@ -99,8 +94,18 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
     }
     return v0;
 }
+// the lanes that hold a total after wave_sum9_scatter, and which
+__device__ __forceinline__ bool gsr_sum9_writer(int lane) { return lane < 16 && ((lane & 2) == 0 || lane == 2); }
+__device__ __forceinline__ int gsr_sum9_slot(int lane) { return lane == 2 ? 8 : (lane & 1) + 2 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1); }
 
 constexpr int NV = 9;  // partial sums per list entry
+
+// Timing ablations (results are WRONG on purpose; never defined in the shipped build): make EXTRA=-DGSR_ABLATE=n
+//   1: plain sum instead of the wave reduction   2: 1 + nothing written to LDS   3: no blend math after the alpha decision
+//   4: nothing after the range test              5: no walk at all (staging + flush only)
+#ifndef GSR_ABLATE
+#define GSR_ABLATE 0
+#endif
 
 // FAST_EXP: G = exp(power) from the hardware exp2 (v_exp_f32, <= 1e-6 relative off gsr_expf_blend on the range that can pass), 2 issue slots
 // instead of the 9 instructions of the forward's fully specified gsr_expf_blend.  The alpha >= 1/255 decision must be the forward's: when
@@ -178,9 +183,9 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
     const uint32_t hi = __builtin_amdgcn_readfirstlane(hi_);
 
     // reduce-scatter constants: lane masks and the accumulator slot this lane writes
-    const unsigned long long M0 = 0xAAAAAAAAAAAAAAAAull, M1 = 0xCCCCCCCCCCCCCCCCull, M2 = 0xF0F0F0F0F0F0F0F0ull,
-                             M8 = 0x0100010001000100ull;
-    const int my_slot = lane < 8 ? (4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1)) : 8;
+    const unsigned long long M0 = 0xAAAAAAAAAAAAAAAAull, M2 = 0x0004000400040004ull;
+    const bool writer = gsr_sum9_writer(lane);
+    const int my_slot = gsr_sum9_slot(lane);
     float* my_acc = s_acc + (NQ == 2 ? 0 : wave * BATCH * NV);
     const int rounds = (int)((hi + BATCH - 1) / BATCH);
 
@@ -248,6 +253,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mm);
                 U |= bq[q];
             }
+            if (GSR_ABLATE >= 5) U = 0ull;
             while (U != 0ull) {
                 const int jj = (int)__builtin_ctzll(U);
                 U &= U - 1ull;
@@ -274,6 +280,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     // compare's result mask): combining them and testing "any lane" is scalar work
                     const unsigned long long m_maybe = act[q] & __builtin_amdgcn_ballot_w64(power >= b.z);  // power > 0: below
                     if (m_maybe == 0ull) return false;
+                    if (GSR_ABLATE >= 4) { T[q] += power; return false; }
                     unsigned long long m_c = m_maybe & __builtin_amdgcn_ballot_w64(power <= 0.0f);
                     float G = FAST_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gsr_expf_blend(power);
                     float alpha = fminf(0.99f, b.y * G);
@@ -284,6 +291,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     }
                     m_c &= __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
                     if (m_c == 0ull) return false;
+                    if (GSR_ABLATE >= 3) { T[q] += alpha; return false; }
                     // From here all 64 lanes run the same straight-line code.  A lane that does not contribute is given alpha = G = 0:
                     // then T/(1-0) = T, its gradient terms vanish, and the colour recurrence (backward.cu:515) leaves accum unchanged
                     float Ge, ae;
@@ -313,8 +321,8 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     if (bl0) {
                         const float wdx = WX0, wdy = W0 * dy;
                         const float tot = wave_sum9_scatter(W0, wdx, wdy, wdx * DX0, wdx * dy, wdy * dy, AT0 * dL0[0], AT0 * dL1[0],
-                                                            AT0 * dL2[0], M0, M1, M2, M8);
-                        if (lane < 9) my_acc[j * NV + my_slot] = tot;
+                                                            AT0 * dL2[0], M0, M2);
+                        if (writer) my_acc[j * NV + my_slot] = tot;
                         wr[w] |= 1ull << jj;
                     }
                 } else if (bl0 || bl1) {  // wave-uniform
@@ -335,8 +343,13 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                         c0 = AT1 * dL0[1]; c1 = AT1 * dL1[1]; c2 = AT1 * dL2[1];
                     }
                     const float swy = sw * dy;
-                    const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M1, M2, M8);
-                    if (lane < 9) atomicAdd(&my_acc[j * NV + my_slot], tot);  // LDS
+#if GSR_ABLATE >= 1
+                    const float tot = ((sw + swx) + (swy + sxx)) + ((swx * dy + swy * dy) + (c0 + c1)) + c2;
+                    if (GSR_ABLATE < 2 ? writer : tot == 12345.678f) atomicAdd(&my_acc[j * NV + my_slot], tot);
+#else
+                    const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M2);
+                    if (writer) atomicAdd(&my_acc[j * NV + my_slot], tot);  // LDS
+#endif
                 }
             }
         }
@@ -374,6 +387,14 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             }
         }
     }
+#if GSR_ABLATE >= 3
+    {   // keeps the ablated walk's arithmetic alive
+        float keep = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) keep += T[q];
+        if (keep == 12345.678f) grad_rows[0] = keep;
+    }
+#endif
     // list entries behind every pixel's last contributor: zero rows (for those that own a row)
     for (uint32_t e = hi + tid; e < total; e += NT) {
         const uint32_t id = point_list[r0 + e];
