@@ -103,6 +103,15 @@ constexpr int NV = 9;  // partial sums per list entry
 // Timing ablations (results are WRONG on purpose; never defined in the shipped build): make EXTRA=-DGSR_ABLATE=n
 //   1: plain sum instead of the wave reduction   2: 1 + nothing written to LDS   3: no blend math after the alpha decision
 //   4: nothing after the range test              5: no walk at all (staging + flush only)
+#ifndef GSR_BWD_WPE
+#define GSR_BWD_WPE 0  // experiment: waves per SIMD the register allocation aims at (0: 6 with one quadrant per wave, 7 with two)
+#endif
+// When an entry's operands are read from LDS: 1 = requested during the previous entry (after its quadrants, before its reduction), 0 = at
+// the top of its own iteration, -1 = by the work split.  Measured in one call, ms: two waves per tile (cfg2) 0.332 / 0.333 piped vs
+// 0.335 / 0.337 not; four waves per tile (2M Gaussians) 0.634 / 0.635 piped vs 0.604 / 0.603 not.
+#ifndef GSR_BWD_PIPE
+#define GSR_BWD_PIPE -1
+#endif
 #ifndef GSR_ABLATE
 #define GSR_ABLATE 0
 #endif
@@ -111,7 +120,7 @@ constexpr int NV = 9;  // partial sums per list entry
 // instead of the 9 instructions of the forward's fully specified gsr_expf_blend.  The alpha >= 1/255 decision must be the forward's: when
 // any lane's alpha lies within 3e-8 of the threshold the wave redoes the entry with gsr_expf_blend, so the blended set is exactly the forward's.
 template <int NQ, bool FAST_EXP>
-__global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? 6 : 7)))
+__global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE ? GSR_BWD_WPE : (NQ == 1 ? 6 : 7))))
 render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ranges,
                        const uint32_t* __restrict__ point_list, const float* __restrict__ splat, const float* __restrict__ bg,
                        const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
@@ -120,6 +129,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
     constexpr int WPT = 4 / NQ;      // waves per tile
     constexpr int NT = 64 * WPT;     // threads
     constexpr int BATCH = 128;       // list entries staged per round (two staging waves)
+    constexpr bool PIPE = GSR_BWD_PIPE < 0 ? NQ == 2 : GSR_BWD_PIPE != 0;
     __shared__ float4 s_a[BATCH];    // mx, my, conic.x, conic.y
     __shared__ float4 s_b[BATCH];    // conic.z, opacity, pthr, -
     __shared__ float4 s_c[BATCH];    // r, g, b, gradient row index (uint bits; 0xFFFFFFFF: nothing to flush)
@@ -254,11 +264,18 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                 U |= bq[q];
             }
             if (GSR_ABLATE >= 5) U = 0ull;
-            while (U != 0ull) {
-                const int jj = (int)__builtin_ctzll(U);
-                U &= U - 1ull;
-                const int j = 64 * w + jj;
-                const float4 a = s_a[j], b = s_b[j], c = s_c[j];
+            if (U == 0ull) continue;
+            // PIPE: the operands of the NEXT entry are requested from LDS after this entry's quadrants have been visited and before its
+            // wave reduction: the registers are free by then and the round trip hides behind the reduction
+            int jj = (int)__builtin_ctzll(U);
+            U &= U - 1ull;
+            int j = 64 * w + jj;
+            // (two register sets taking turns -- the loop body exists twice -- so that nothing is copied between iterations)
+            float4 opA0 = s_a[j], opB0 = s_b[j], opC0 = s_c[j], opA1, opB1, opC1;
+            auto entry = [&](const float4& pa, const float4& pb, const float4& pc, float4& na, float4& nb, float4& nc)
+                             __attribute__((always_inline)) -> bool {
+                float4 a, b, c;
+                if (PIPE) { a = pa; b = pb; c = pc; } else { a = s_a[j]; b = s_b[j]; c = s_c[j]; }
                 const uint32_t kidx = kbase - (uint32_t)j;
                 const float dy = a.y - pyf;  // the wave's quadrants lie side by side: one dy per lane
                 // what a blending quadrant leaves for the sums: w = G * dL/dalpha, dx, alpha * T (NQ = 2: combined below)
@@ -317,6 +334,11 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                 };
                 const bool bl0 = visit(std::integral_constant<int, 0>{}, W0, WX0, DX0, AT0);
                 const bool bl1 = NQ > 1 ? visit(std::integral_constant<int, NQ - 1>{}, W1, WX1, DX1, AT1) : false;
+                const bool more = U != 0ull;
+                const int jjn = more ? (int)__builtin_ctzll(U) : jj;
+                U &= U - 1ull;
+                const int jn = 64 * w + jjn;
+                if (PIPE) { na = s_a[jn]; nb = s_b[jn]; nc = s_c[jn]; }
                 if constexpr (NQ == 1) {  // one quadrant per wave
                     if (bl0) {
                         const float wdx = WX0, wdy = W0 * dy;
@@ -351,7 +373,10 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     if (writer) atomicAdd(&my_acc[j * NV + my_slot], tot);  // LDS
 #endif
                 }
-            }
+                jj = jjn; j = jn;
+                return more;
+            };
+            while (entry(opA0, opB0, opC0, opA1, opB1, opC1) && entry(opA1, opB1, opC1, opA0, opB0, opC0)) {}
         }
         if (NQ != 2 && lane == 0) { s_wr[wave][0] = wr[0]; s_wr[wave][1] = wr[1]; }
         __syncthreads();
@@ -433,7 +458,7 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
     if (nq != 1 && nq != 2) nq = (mean_list < (float)gsr_variant("BWD_NQ_LIST", 700) && gx * gy >= gsr_variant("BWD_NQ_TILES", 4096)) ? 2 : 1;
     const bool fast = gsr_variant("BWD_FASTEXP", 1) != 0;
 #define GSR_BWD_LAUNCH(NQ_, F_)                                                                                                  \
-    hipLaunchKernelGGL((render_backward_kernel<NQ_, F_>), dim3(gx * gy), dim3(64 * (4 / NQ_)), 0, s, W, H, gx, gy, order, ranges, \
+    hipLaunchKernelGGL((render_backward_kernel<NQ_, F_>), dim3(gx * gy), dim3(64 * (4 / NQ_)), (size_t)gsr_variant("BWD_PADLDS", 0), s, W, H, gx, gy, order, ranges, \
                        point_list, splat, bg, final_T, n_contrib, dL_dpix, grad_rows)
     if (nq == 2) { if (fast) GSR_BWD_LAUNCH(2, true); else GSR_BWD_LAUNCH(2, false); }
     else { if (fast) GSR_BWD_LAUNCH(1, true); else GSR_BWD_LAUNCH(1, false); }
