@@ -99,16 +99,20 @@ __device__ __forceinline__ bool gsr_sum9_writer(int lane) { return lane < 16 && 
 __device__ __forceinline__ int gsr_sum9_slot(int lane) { return lane == 2 ? 8 : (lane & 1) + 2 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1); }
 
 constexpr int NV = 9;  // partial sums per list entry
+constexpr uint32_t GSR_NO_ROW = 0x0FFFFFFFu;  // 28 bits of gradient-row index (the host refuses more instances), 4 of quadrant mask
 
 // Timing ablations (results are WRONG on purpose; never defined in the shipped build): make EXTRA=-DGSR_ABLATE=n
 //   1: plain sum instead of the wave reduction   2: 1 + nothing written to LDS   3: no blend math after the alpha decision
 //   4: nothing after the range test              5: no walk at all (staging + flush only)
 #ifndef GSR_BWD_WPE
-#define GSR_BWD_WPE 0  // experiment: waves per SIMD the register allocation aims at (0: 6 with one quadrant per wave, 7 with two)
+#define GSR_BWD_WPE 0  // experiment: waves per SIMD the register allocation aims at (0: 6 with one quadrant per wave, 8 with two)
 #endif
 // When an entry's operands are read from LDS: 1 = requested during the previous entry (after its quadrants, before its reduction), 0 = at
 // the top of its own iteration, -1 = by the work split.  Measured in one call, ms: two waves per tile (cfg2) 0.332 / 0.333 piped vs
 // 0.335 / 0.337 not; four waves per tile (2M Gaussians) 0.634 / 0.635 piped vs 0.604 / 0.603 not.
+#ifndef GSR_BWD_BATCH1
+#define GSR_BWD_BATCH1 128  // entries per round with four waves per tile (64: half the LDS, 8 instead of 6 waves per SIMD, twice the rounds)
+#endif
 #ifndef GSR_BWD_PIPE
 #define GSR_BWD_PIPE -1
 #endif
@@ -120,7 +124,7 @@ constexpr int NV = 9;  // partial sums per list entry
 // instead of the 9 instructions of the forward's fully specified gsr_expf_blend.  The alpha >= 1/255 decision must be the forward's: when
 // any lane's alpha lies within 3e-8 of the threshold the wave redoes the entry with gsr_expf_blend, so the blended set is exactly the forward's.
 template <int NQ, bool FAST_EXP>
-__global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE ? GSR_BWD_WPE : (NQ == 1 ? 6 : 7))))
+__global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE ? GSR_BWD_WPE : (NQ == 1 ? 6 : 8))))
 render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ranges,
                        const uint32_t* __restrict__ point_list, const float* __restrict__ splat, const float* __restrict__ bg,
                        const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
@@ -128,18 +132,21 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
 {
     constexpr int WPT = 4 / NQ;      // waves per tile
     constexpr int NT = 64 * WPT;     // threads
-    constexpr int BATCH = 128;       // list entries staged per round (two staging waves)
+    constexpr int BATCH = NQ == 1 ? GSR_BWD_BATCH1 : 128;  // list entries staged per round
+    constexpr int SW = BATCH / 64;                          // staging waves
     constexpr bool PIPE = GSR_BWD_PIPE < 0 ? NQ == 2 : GSR_BWD_PIPE != 0;
     __shared__ float4 s_a[BATCH];    // mx, my, conic.x, conic.y
-    __shared__ float4 s_b[BATCH];    // conic.z, opacity, pthr, -
-    __shared__ float4 s_c[BATCH];    // r, g, b, gradient row index (uint bits; 0xFFFFFFFF: nothing to flush)
+    __shared__ float4 s_b[BATCH];    // conic.z, opacity, pthr, r
+    __shared__ float2 s_c[BATCH];    // g, b
+    // gradient row index (GSR_NO_ROW: nothing to flush) | quadrants the splat can reach << 28.  44 bytes per entry + 36 of sums: with two
+    // waves per tile the workgroup's LDS is exactly 10,240 bytes = 1/16 of the CU's 160 KB, eight waves per SIMD
+    __shared__ uint32_t s_row[BATCH];
     // wave totals of the batch's entries.  NQ = 2: ONE zero-initialised row per entry, the two waves add into it with LDS float atomics
     // (two addends: the sum does not depend on their order).  NQ = 1: a row per wave, summed in wave order when the batch is flushed;
     // s_wr marks the rows a wave has written (nothing is zeroed).
     __shared__ float s_acc[(NQ == 2 ? 1 : WPT) * BATCH * NV];
-    __shared__ unsigned long long s_wr[WPT][2];
-    __shared__ unsigned long long s_qm[4][2];  // per quadrant, per staging wave: the staged entries that can reach it
-    __shared__ uint32_t s_max[WPT];
+    __shared__ unsigned long long s_wr[WPT][SW];
+    uint32_t* s_max = reinterpret_cast<uint32_t*>(s_acc);  // [WPT], only before the first round
 
     // 1-D launch in `order` (tiles by descending list length, binning.hip); NULL = row-major
     const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;
@@ -203,7 +210,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
         // ---- stage this batch (back to front): one record per thread; instances whose tile the splat cannot reach own no
         // gradient row (gsr_reach_mask, preprocess) and are dropped ----
         const uint32_t progress = (uint32_t)i * BATCH + tid;
-        uint32_t qm = 0, row = 0xFFFFFFFFu;
+        uint32_t qm = 0, row = GSR_NO_ROW;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
         float pthr = 0.f;
         if (tid < BATCH && progress < hi) {
@@ -232,15 +239,14 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             }
             // an instance that owns a row but reaches no quadrant (the two tests round differently) is flushed as a zero row
             if (keep) qm = gsr_quad_mask(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0);
-            if (!keep) row = 0xFFFFFFFFu;
+            if (!keep) row = GSR_NO_ROW;
         }
-        const unsigned long long b0 = __ballot(qm & 1u), b1 = __ballot(qm & 2u), b2 = __ballot(qm & 4u), b3 = __ballot(qm & 8u);
         __syncthreads();  // previous batch flushed
         if (tid < BATCH) {
-            if (lane == 0) { s_qm[0][wave] = b0; s_qm[1][wave] = b1; s_qm[2][wave] = b2; s_qm[3][wave] = b3; }
             s_a[tid] = q0;
-            s_b[tid] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), 0.f);  // clamp: see the forward
-            s_c[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(row));
+            s_b[tid] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), q1.z);  // clamp: see the forward
+            s_c[tid] = make_float2(q1.w, q2.x);
+            s_row[tid] = row | (qm << 28);
             if constexpr (NQ == 2) {
 #pragma unroll
                 for (int t = 0; t < NV; t++) s_acc[tid * NV + t] = 0.f;
@@ -250,17 +256,15 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
 
         // ---- walk the staged entries that can reach this wave's quadrants ----
         const uint32_t kbase = hi - 1u - (uint32_t)i * BATCH;  // list position of staged entry j = kbase - j (scalar)
-        unsigned long long wr[2] = {0ull, 0ull};
+        unsigned long long wr[SW] = {};
 #pragma unroll
-        for (int w = 0; w < 2; w++) {
+        for (int w = 0; w < SW; w++) {
             unsigned long long bq[NQ];
             unsigned long long U = 0ull;
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
-                const unsigned long long mm = s_qm[q_first + q][w];
-                // (readfirstlane returns int: without the uint32_t casts the low half would be sign-extended over the high half)
-                bq[q] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mm >> 32)) << 32) |
-                        (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mm);
+                // the staged entries that can reach quadrant q: a ballot over the bits the staging threads left beside the row index
+                bq[q] = __builtin_amdgcn_ballot_w64(((s_row[64 * w + lane] >> (28 + q_first + q)) & 1u) != 0u);
                 U |= bq[q];
             }
             if (GSR_ABLATE >= 5) U = 0ull;
@@ -271,10 +275,12 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             U &= U - 1ull;
             int j = 64 * w + jj;
             // (two register sets taking turns -- the loop body exists twice -- so that nothing is copied between iterations)
-            float4 opA0 = s_a[j], opB0 = s_b[j], opC0 = s_c[j], opA1, opB1, opC1;
-            auto entry = [&](const float4& pa, const float4& pb, const float4& pc, float4& na, float4& nb, float4& nc)
+            float4 opA0 = s_a[j], opB0 = s_b[j], opA1, opB1;
+            float2 opC0 = s_c[j], opC1;
+            auto entry = [&](const float4& pa, const float4& pb, const float2& pc, float4& na, float4& nb, float2& nc)
                              __attribute__((always_inline)) -> bool {
-                float4 a, b, c;
+                float4 a, b;
+                float2 c;
                 if (PIPE) { a = pa; b = pb; c = pc; } else { a = s_a[j]; b = s_b[j]; c = s_c[j]; }
                 const uint32_t kidx = kbase - (uint32_t)j;
                 const float dy = a.y - pyf;  // the wave's quadrants lie side by side: one dy per lane
@@ -321,7 +327,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     // is ever used, and it obeys the same recurrence with the scalar c . dL/dpixel in place of the colour: one
                     // register per pixel instead of three, 6 instructions instead of 12.  `behind` = accum . dL/dpixel of the
                     // entries behind this one (the recurrence already applied for the previous entry)
-                    const float cdl = __builtin_fmaf(c.z, dL2[q], __builtin_fmaf(c.y, dL1[q], c.x * dL0[q]));
+                    const float cdl = __builtin_fmaf(c.y, dL2[q], __builtin_fmaf(c.x, dL1[q], b.w * dL0[q]));
                     float dL_dalpha = cdl - behind[q];
                     behind[q] = __builtin_fmaf(ae, cdl, oma * behind[q]);
                     dL_dalpha *= T[q];
@@ -378,12 +384,15 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             };
             while (entry(opA0, opB0, opC0, opA1, opB1, opC1) && entry(opA1, opB1, opC1, opA0, opB0, opC0)) {}
         }
-        if (NQ != 2 && lane == 0) { s_wr[wave][0] = wr[0]; s_wr[wave][1] = wr[1]; }
+        if (NQ != 2 && lane == 0) {
+#pragma unroll
+            for (int w = 0; w < SW; w++) s_wr[wave][w] = wr[w];
+        }
         __syncthreads();
         // ---- flush: entry `tid` of the batch -> one 48-byte row ----
         if (tid < BATCH) {
-            const uint32_t frow = __float_as_uint(s_c[tid].w);
-            if (frow != 0xFFFFFFFFu) {
+            const uint32_t frow = s_row[tid] & GSR_NO_ROW;
+            if (frow != GSR_NO_ROW) {
                 float r[NV];
                 if constexpr (NQ == 2) {
 #pragma unroll
