@@ -229,7 +229,7 @@ void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint3
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int wave8x8 = gsr_variant("WAVE8X8", 1);
     if (wave8x8 && gsr_variant("QUAD", 1))
-        hipLaunchKernelGGL((render_forward_kernel<true>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, gsr_variant("QUAD", 1) == 2 ? 2 : 1, order, ranges, point_list, splat, bg,
+        hipLaunchKernelGGL((render_forward_kernel<true>), dim3(gx * gy), dim3(256), (size_t)gsr_variant("FWD_PADLDS", 0), s, W, H, gx, gy, gsr_variant("QUAD", 1) == 2 ? 2 : 1, order, ranges, point_list, splat, bg,
                            final_T, n_contrib, out_color);
     else
         hipLaunchKernelGGL((render_forward_kernel<false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
