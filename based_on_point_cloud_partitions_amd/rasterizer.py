@@ -220,12 +220,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
                               imgBuffer)
         ctx.mark_non_differentiable(radii)
+        # autograd would otherwise materialise a zero "gradient" for the int32 radii on every backward (a 500k-element fill kernel
+        # between the two blend kernels, 5 us per step on the benchmark); the reference's Function lets it (__init__.py:99-101)
+        ctx.set_materialize_grads(False)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
+        if grad_out_color is None:  # only possible with set_materialize_grads(False): nothing flowed into the image
+            grad_out_color = torch.zeros((NUM_CHANNELS, raster_settings.image_height, raster_settings.image_width),
+                                         dtype=torch.float32, device=ctx.saved_tensors[1].device)
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = ctx.saved_tensors
         args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations, raster_settings.scale_modifier,
                 cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
