@@ -14,6 +14,10 @@
 
 namespace {
 
+#ifndef GSR_FWD_GROUP
+#define GSR_FWD_GROUP 4  // entries per turn of the walk (the all-pixels-done test runs once per turn)
+#endif
+
 template <bool QUAD>
 __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, int gy, int wave8x8, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
@@ -22,8 +26,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                              float* __restrict__ out_color)
 {
-    __shared__ float4 s_a[260];  // mx, my, conic.x, conic.y          (+4: padding entries for the unrolled walk)
-    __shared__ float4 s_b[260];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
+    __shared__ float4 s_a[256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)];  // mx, my, conic.x, conic.y          (+4: padding entries for the unrolled walk)
+    __shared__ float4 s_b[256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
     __shared__ float4 s_c[256];  // r, g, b, Gaussian id (uint bits)
     __shared__ int s_done[4];
     __shared__ int s_wcnt[4];    // entries each wave keeps after the tile-level rejection
@@ -54,7 +58,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     float px = inside ? pixf_x : PARKED;
     bool wave_done = !gsr_any(px != PARKED);
 
-    if (QUAD && tid < 4) {  // padding entries that can never pass the range test (the walk takes entries four at a time)
+    if (QUAD && tid < (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)) {  // padding entries that can never pass the range test (the walk takes entries four at a time)
         s_a[256 + tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
         s_b[256 + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
     }
@@ -94,14 +98,14 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                 (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
             while (m != 0ull) {
                 // the next (up to) four entries of this wave; missing ones are the padding entry
-                int jj[4];
+                int jj[GSR_FWD_GROUP];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < GSR_FWD_GROUP; u++) {
                     jj[u] = m != 0ull ? 64 * w + (int)__builtin_ctzll(m) : 256 + u;
                     m &= m - 1ull;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < GSR_FWD_GROUP; u++) {
                     const int j = jj[u];
                     const float4 a = s_a[j];
                     const float4 b = s_b[j];
