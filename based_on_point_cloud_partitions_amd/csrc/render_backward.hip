@@ -105,7 +105,7 @@ constexpr uint32_t GSR_NO_ROW = 0x0FFFFFFFu;  // 28 bits of gradient-row index (
 //   1: plain sum instead of the wave reduction   2: 1 + nothing written to LDS   3: no blend math after the alpha decision
 //   4: nothing after the range test              5: no walk at all (staging + flush only)
 #ifndef GSR_BWD_WPE
-#define GSR_BWD_WPE 0  // experiment: waves per SIMD the register allocation aims at (0: 6 with one quadrant per wave, 8 with two)
+#define GSR_BWD_WPE 0  // experiment: waves per SIMD the register allocation aims at (0: 8)
 #endif
 // When an entry's operands are read from LDS: 1 = requested during the previous entry (after its quadrants, before its reduction), 0 = at
 // the top of its own iteration, -1 = by the work split.  Measured in one call, ms: two waves per tile (cfg2) 0.332 / 0.333 piped vs
@@ -124,7 +124,7 @@ constexpr uint32_t GSR_NO_ROW = 0x0FFFFFFFu;  // 28 bits of gradient-row index (
 // instead of the 9 instructions of the forward's fully specified gsr_expf_blend.  The alpha >= 1/255 decision must be the forward's: when
 // any lane's alpha lies within 3e-8 of the threshold the wave redoes the entry with gsr_expf_blend, so the blended set is exactly the forward's.
 template <int NQ, bool FAST_EXP>
-__global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE ? GSR_BWD_WPE : (NQ == 1 ? 6 : 8))))
+__global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE ? GSR_BWD_WPE : 8)))
 render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ranges,
                        const uint32_t* __restrict__ point_list, const float* __restrict__ splat, const float* __restrict__ bg,
                        const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
@@ -141,11 +141,11 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
     // gradient row index (GSR_NO_ROW: nothing to flush) | quadrants the splat can reach << 28.  44 bytes per entry + 36 of sums: with two
     // waves per tile the workgroup's LDS is exactly 10,240 bytes = 1/16 of the CU's 160 KB, eight waves per SIMD
     __shared__ uint32_t s_row[BATCH];
-    // wave totals of the batch's entries.  NQ = 2: ONE zero-initialised row per entry, the two waves add into it with LDS float atomics
-    // (two addends: the sum does not depend on their order).  NQ = 1: a row per wave, summed in wave order when the batch is flushed;
-    // s_wr marks the rows a wave has written (nothing is zeroed).
-    __shared__ float s_acc[(NQ == 2 ? 1 : WPT) * BATCH * NV];
-    __shared__ unsigned long long s_wr[WPT][SW];
+    // wave totals of the batch's entries: zero-initialised rows that TWO waves add into with LDS float atomics (two addends: the sum does
+    // not depend on their order).  NQ = 2: one row per entry; NQ = 1: one per wave pair, the two added in fixed order when the batch is
+    // flushed (a row per wave took 24 KB of LDS per workgroup: 6 waves per SIMD; now 15 KB: 8)
+    constexpr int NACC = NQ == 2 ? 1 : 2;
+    __shared__ float s_acc[NACC * BATCH * NV];
     uint32_t* s_max = reinterpret_cast<uint32_t*>(s_acc);  // [WPT], only before the first round
 
     // 1-D launch in `order` (tiles by descending list length, binning.hip); NULL = row-major
@@ -203,7 +203,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
     const unsigned long long M0 = 0xAAAAAAAAAAAAAAAAull, M2 = 0x0004000400040004ull;
     const bool writer = gsr_sum9_writer(lane);
     const int my_slot = gsr_sum9_slot(lane);
-    float* my_acc = s_acc + (NQ == 2 ? 0 : wave * BATCH * NV);
+    float* my_acc = s_acc + (NQ == 2 ? 0 : (wave >> 1) * BATCH * NV);
     const int rounds = (int)((hi + BATCH - 1) / BATCH);
 
     for (int i = 0; i < rounds; i++) {
@@ -247,16 +247,13 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             s_b[tid] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), q1.z);  // clamp: see the forward
             s_c[tid] = make_float2(q1.w, q2.x);
             s_row[tid] = row | (qm << 28);
-            if constexpr (NQ == 2) {
 #pragma unroll
-                for (int t = 0; t < NV; t++) s_acc[tid * NV + t] = 0.f;
-            }
+            for (int t = 0; t < NACC * NV; t++) s_acc[(t / NV) * BATCH * NV + tid * NV + (t % NV)] = 0.f;
         }
         __syncthreads();
 
         // ---- walk the staged entries that can reach this wave's quadrants ----
         const uint32_t kbase = hi - 1u - (uint32_t)i * BATCH;  // list position of staged entry j = kbase - j (scalar)
-        unsigned long long wr[SW] = {};
 #pragma unroll
         for (int w = 0; w < SW; w++) {
             unsigned long long bq[NQ];
@@ -350,8 +347,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                         const float wdx = WX0, wdy = W0 * dy;
                         const float tot = wave_sum9_scatter(W0, wdx, wdy, wdx * DX0, wdx * dy, wdy * dy, AT0 * dL0[0], AT0 * dL1[0],
                                                             AT0 * dL2[0], M0, M2);
-                        if (writer) my_acc[j * NV + my_slot] = tot;
-                        wr[w] |= 1ull << jj;
+                        if (writer) atomicAdd(&my_acc[j * NV + my_slot], tot);  // LDS
                     }
                 } else if (bl0 || bl1) {  // wave-uniform
                     // the lane's two pixels share dy: the y moments of their sum are products of the x moments with dy
@@ -384,29 +380,14 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             };
             while (entry(opA0, opB0, opC0, opA1, opB1, opC1) && entry(opA1, opB1, opC1, opA0, opB0, opC0)) {}
         }
-        if (NQ != 2 && lane == 0) {
-#pragma unroll
-            for (int w = 0; w < SW; w++) s_wr[wave][w] = wr[w];
-        }
         __syncthreads();
         // ---- flush: entry `tid` of the batch -> one 48-byte row ----
         if (tid < BATCH) {
             const uint32_t frow = s_row[tid] & GSR_NO_ROW;
             if (frow != GSR_NO_ROW) {
                 float r[NV];
-                if constexpr (NQ == 2) {
 #pragma unroll
-                    for (int t = 0; t < NV; t++) r[t] = s_acc[tid * NV + t];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < NV; t++) r[t] = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WPT; w++)  // waves in fixed order
-                        if ((s_wr[w][tid >> 6] >> (tid & 63)) & 1ull) {
-#pragma unroll
-                            for (int t = 0; t < NV; t++) r[t] += s_acc[(w * BATCH + tid) * NV + t];
-                        }
-                }
+                for (int t = 0; t < NV; t++) r[t] = NACC == 1 ? s_acc[tid * NV + t] : s_acc[tid * NV + t] + s_acc[(BATCH + tid) * NV + t];
                 // per-Gaussian factors of backward.cu:538-554 applied once to the reduced moments
                 const float4 a = s_a[tid];
                 const float4 b = s_b[tid];
