@@ -444,7 +444,8 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
     int nq = gsr_variant("BWD_NQ", 0);
     // two quadrants per wave pay when the lists are short AND the image has enough tiles to fill the chip with half as many waves
     // (measured at 1080p, ms, NQ = 2 vs 1: 500k Gaussians, mean list 467: 0.374 vs 0.397; 1M, 930: 0.461 vs 0.434; 1.5M, 1400: 0.609 vs 0.521;
-    // 2M, 1866: 0.745 vs 0.636; and 10k Gaussians at 256x256, 256 tiles: 0.121 vs 0.064)
+    // 2M, 1866: 0.745 vs 0.636; and 10k Gaussians at 256x256, 256 tiles: 0.121 vs 0.064; with the final kernels, mean list ~400: 300k Gaussians at
+    // 800x800, 2,500 tiles: 0.339 vs 0.192; 150k at 640x360, 920 tiles: 0.394 vs 0.204 -- few tiles leave the longest list's waves alone on the chip)
     if (nq != 1 && nq != 2) nq = (mean_list < (float)gsr_variant("BWD_NQ_LIST", 700) && gx * gy >= gsr_variant("BWD_NQ_TILES", 4096)) ? 2 : 1;
     const bool fast = gsr_variant("BWD_FASTEXP", 1) != 0;
 #define GSR_BWD_LAUNCH(NQ_, F_)                                                                                                  \

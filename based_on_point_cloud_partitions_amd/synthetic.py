@@ -159,6 +159,9 @@ CONFIGS = {
     # place the list-length threshold between the two work splits of the blend backward
     "dense1m": dict(P=1_000_000, W=1920, H=1080, focal=1200.0, cameras=16),
     "dense1m5": dict(P=1_500_000, W=1920, H=1080, focal=1200.0, cameras=16),
+    # ... and two smaller images of the same scene (2,500 / 920 tiles), used to place the tile-count threshold of that choice
+    "mid800": dict(P=300_000, W=800, H=800, focal=600.0, cameras=8),
+    "mid640": dict(P=150_000, W=640, H=360, focal=400.0, cameras=8),
 }
 
 
