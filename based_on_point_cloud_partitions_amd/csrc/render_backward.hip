@@ -2,7 +2,8 @@
 //
 // The reference issues 9 global float atomicAdds per contributing (pixel, Gaussian) pair (backward.cu:523,545-554).  On MI355X global
 // float atomics top out near 1.3 TB/s chip-wide and collapse when lanes scatter, so this kernel never uses them: the 9 partial sums
-// of a list entry are reduced across the 64 lanes of a wave with DPP adds (fixed tree), the waves of a tile are combined through LDS,
+// of a list entry are reduced across the 64 lanes of a wave with DPP adds (fixed tree), the waves of a tile are combined in LDS (float
+// atomics with exactly two addends per row: order-independent),
 // and every reachable (Gaussian, tile) instance writes ONE 48-byte gradient row with plain stores.  Rows are numbered per Gaussian
 // (first row + rank of the tile among the tiles its splat can reach, gsr_reach_mask), so the rows of one Gaussian are contiguous and
 // the per-Gaussian kernel sums them in a fixed order: gradients are bitwise reproducible run to run, unlike the reference's.
@@ -15,10 +16,10 @@
 //   NQ = 2: two waves per tile (128 threads), a 16x8 half each.  A lane's two pixels lie in the same image row, so they share dy: each
 //           blending quadrant leaves (w, w*dx, dx, alpha*T), the two are combined as S w, S w*dx, S w*dx^2, S alpha*T*dL/dpixel, and the y
 //           moments are S w*dy = (S w)*dy, S w*dx*dy = (S w*dx)*dy, S w*dy^2 = (S w*dy)*dy -- 14 instructions for a pair, 8 for a single
-//           quadrant -- and reduced once per (entry, half): 1.87M reductions (13 DPP + 15 selects + 2 permlane swaps, a third of the
-//           instructions of a blending instance).  A wave walks twice the pixels, so a tile's critical path is twice as long: faster
-//           where lists are short (500k Gaussians at 1080p: 0.338 vs 0.375 ms), slower where every tile's list is long (2M: 0.745 vs
-//           0.636 ms) or the image has few tiles.  The launcher picks by the mean list length and the tile count.  (NQ = 4, one wave
+//           quadrant -- and reduced once per (entry, half): 1.87M reductions (18 DPP adds + 3 selects + 2 permlane swaps).  A wave walks twice
+//           the pixels, so a tile's critical path is twice as long: faster where lists are short and tiles many (500k Gaussians at
+//           1080p: 0.325 vs 0.348 ms), slower where every tile's list is long (2M: 0.745 vs 0.636 ms) or the image has few tiles
+//           (800x800: 0.339 vs 0.192).  The launcher picks by the mean list length and the tile count.  (NQ = 4, one wave
 //           per tile and 1.22M reductions, was built and measured in round 3: fewest instructions, but the longest tiles alone set the
 //           kernel's duration.)
 // The quadrants of an entry are visited under SCALAR branches: which staged entries can reach which quadrant (gsr_quad_mask) is a
