@@ -311,6 +311,10 @@ def main():
                     help="memory order of the Gaussians: the workload's own (random, BASELINE.md) or sorted by the Morton code of xyz "
                          "(what a trainer gets by re-ordering its model at densification time; not the headline workload)")
     ap.add_argument("--no-stage-timers", action="store_true", help="time the region without per-stage HIP events")
+    ap.add_argument("--spinup-ms", type=float, default=1500.0,
+                    help="untimed steps run for this long before the warm-up, so that the clocks of a fresh box have settled: the same "
+                         "process on the same box measured 0.737-0.741 ms/step with 0 ms, 0.739 with 400 ms, 0.724 with 2000 ms "
+                         "(render_backward 0.333 -> 0.327 ms: the GPU's clocks ramp up over the first second of sustained load)")
     ap.add_argument("--full-step", action="store_true",
                     help="also time the step from raw parameters (activations fused or not) and with the L1/SSIM loss (train.py:107-118)")
     args = ap.parse_args()
@@ -418,6 +422,15 @@ def main():
     _lib.profile_enable(False)
     _lib.profile_collect()
     _lib.profile_enable(use_timers)
+    if args.spinup_ms > 0:  # not part of the W warm-up steps: brings a cold GPU to its steady clocks
+        _lib.profile_enable(False)
+        t_spin, k = time.perf_counter(), 0
+        while 1e3 * (time.perf_counter() - t_spin) < args.spinup_ms:
+            for _ in range(8):
+                step(k)
+                k += 1
+            torch.cuda.synchronize()
+        _lib.profile_enable(use_timers)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
