@@ -303,7 +303,7 @@ def kernel_source_hash():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="cfg2", choices=sorted(syn.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -311,10 +311,11 @@ def main():
                     help="memory order of the Gaussians: the workload's own (random, BASELINE.md) or sorted by the Morton code of xyz "
                          "(what a trainer gets by re-ordering its model at densification time; not the headline workload)")
     ap.add_argument("--no-stage-timers", action="store_true", help="time the region without per-stage HIP events")
-    ap.add_argument("--spinup-ms", type=float, default=1500.0,
-                    help="untimed steps run for this long before the warm-up, so that the clocks of a fresh box have settled: the same "
-                         "process on the same box measured 0.737-0.741 ms/step with 0 ms, 0.739 with 400 ms, 0.724 with 2000 ms "
-                         "(render_backward 0.333 -> 0.327 ms: the GPU's clocks ramp up over the first second of sustained load)")
+    ap.add_argument("--spinup-ms", type=float, default=6000.0,
+                    help="upper limit of the untimed spin-up before the warm-up: batches of 64 steps run until four in a row bring no "
+                         "improvement of 0.5 %% (at least 0.5 s).  A fresh box's GPU reaches its steady clocks only after a second or more of "
+                         "sustained load: same process, same box, 0.737-0.741 ms/step with no spin-up, 0.739 with 0.4 s, 0.724 with 2 s "
+                         "(render_backward 0.333 -> 0.327 ms); 0 switches it off")
     ap.add_argument("--full-step", action="store_true",
                     help="also time the step from raw parameters (activations fused or not) and with the L1/SSIM loss (train.py:107-118)")
     args = ap.parse_args()
@@ -419,32 +420,50 @@ def main():
     #  - the timed region carries events around that stage only (its duration feeds `roofline`);
     #  - an untimed pass after the timed region, all events on, fills in the per-stage table (`roofline_kernels`).
     use_timers = not args.no_stage_timers
+    # the interpreter's cyclic collector is kept out of the timed region (a generation-2 pass over torch's heap is a multi-millisecond
+    # host stall); everything is collected here, before the warm-up
+    import gc
+    gc.collect()
     _lib.profile_enable(False)
     _lib.profile_collect()
     _lib.profile_enable(use_timers)
-    if args.spinup_ms > 0:  # not part of the W warm-up steps: brings a cold GPU to its steady clocks
-        _lib.profile_enable(False)
-        t_spin, k = time.perf_counter(), 0
-        while 1e3 * (time.perf_counter() - t_spin) < args.spinup_ms:
-            for _ in range(8):
-                step(k)
-                k += 1
-            torch.cuda.synchronize()
-        _lib.profile_enable(use_timers)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     _lib.profile_enable(False)
     warm = _lib.profile_collect() if use_timers else {}
     dominant = max(warm, key=lambda k: warm[k][0] / max(warm[k][1], 1)) if any(n for _, n in warm.values()) else "render_backward"
+    # Spin-up (untimed, beyond the W warm-up steps): a GPU that has idled -- a fresh box, but also the tens of milliseconds of host
+    # work between two phases of this script -- runs its first ~30 ms of work at lower clocks.  Measured in one process: batches of 64
+    # steps settle at 0.700 ms/step, a 48-step region timed right after an idle gap reads 0.735.  So batches of 64 steps run until four in
+    # a row bring no improvement of 0.5 % (at least 0.5 s, at most --spinup-ms), and the timed region starts right behind the last one.
+    spinup = None
+    if args.spinup_ms > 0:
+        t_spin, k, best, flat, batches = time.perf_counter(), 0, float("inf"), 0, []
+        while 1e3 * (time.perf_counter() - t_spin) < args.spinup_ms:
+            tb0 = time.perf_counter()
+            for _ in range(64):
+                step(k)
+                k += 1
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - tb0) / 64
+            batches.append(round(1e3 * dt, 4))
+            if dt < 0.995 * best:
+                best, flat = dt, 0
+            else:
+                flat += 1
+            if flat >= 4 and time.perf_counter() - t_spin > 0.5:
+                break
+        spinup = {"steps": k, "ms": round(1e3 * (time.perf_counter() - t_spin), 1), "first_batch_ms_per_step": batches[0],
+                  "last_batch_ms_per_step": batches[-1]}
+        if dist is not None:  # ranks leave their spin-up at different times: align, then 32 more steps so that nobody starts cold
+            dist.barrier()
+            for i in range(32):
+                step(i)
+    _lib.profile_enable(use_timers, stages=[dominant])
+    gc.disable()
     if dist is not None:
         dist.barrier()
-    _lib.profile_enable(use_timers, stages=[dominant])
-    # the interpreter's cyclic collector is kept out of the timed region (a generation-2 pass over torch's heap is a multi-millisecond
-    # host stall: two of ~60 runs in round 3 showed +0.1 ms per step with unchanged kernel times); everything is collected before it
-    import gc
-    gc.collect()
-    gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -602,6 +621,7 @@ def main():
                                "instances_listed_mean": round(float(np.mean([u["listed"] for u in used])), 1),
                                "per_camera": [{"V": u["V"], "R": u["R"], "tile_list_mean": round(u["tile_mean"], 1),
                                                "tile_list_max": u["tile_max"], "listed": u["listed"]} for u in stats]},
+            "spinup": spinup,  # untimed steps before the W warm-up steps (clock ramp of a cold GPU), see --spinup-ms
             "ms_per_step_reference_lists": round(ref_lists_ms, 4) if ref_lists_ms is not None else None,
             "knn_init_ms": knn_ms,
             "knn_points_per_s": round(P / (knn_ms * 1e-3), 1),
