@@ -473,11 +473,11 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     const GeomLayout G = gsr_geom_layout(P);
     const ImageLayout I = gsr_image_layout(W, H);
     const BinLayout B = gsr_bin_layout((long)R, P, W, H);
+    // render_backward keeps a gradient-row index in 28 bits beside the 4-bit quadrant mask (rows <= instances)
+    if (R >= 0x0FFFFFFF) return fail(-1, "num_rendered out of range (the backward keeps gradient-row indices in 28 bits)");
     if (geom_bytes < G.bytes || image_bytes < I.bytes) return fail(-3, "state buffer too small");
     if (R > 0 && (!binning_buffer || binning_bytes < B.bytes)) return fail(-3, "binning buffer too small");
     if (R > 0 && (!scratch || scratch_bytes < gsr_backward_scratch_bytes(R, W, H))) return fail(-3, "backward scratch too small");
-    // render_backward keeps a gradient-row index in 28 bits beside the 4-bit quadrant mask (rows <= instances)
-    if (R >= 0x0FFFFFFF) return fail(-1, "num_rendered out of range (the backward keeps gradient-row indices in 28 bits)");
     const char* g = (const char*)geom_buffer;
     const char* b = (const char*)binning_buffer;
     const char* im = (const char*)image_buffer;

@@ -8,7 +8,7 @@ for flags in "$@"; do
   n=$((n+1))
   rm -f $file.o
   make EXTRA="$flags" > $out/build_$n.log 2>&1 || { echo "build failed: $flags"; tail -3 $out/build_$n.log; continue; }
-  ( cd ../.. && timeout -k 10 200 python bench.py --config $cfg --steps 48 --warmup 8 --no-cpu-baseline > $out/b_$n.log 2>&1
+  ( cd ../.. && timeout -k 10 200 python bench.py --config $cfg --steps 256 --warmup 8 --no-cpu-baseline > $out/b_$n.log 2>&1
     python3 - <<PY
 import json
 d=json.loads([l for l in open("$out/b_$n.log") if l.startswith("{")][-1])
