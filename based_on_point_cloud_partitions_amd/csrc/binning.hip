@@ -68,6 +68,12 @@ __device__ __forceinline__ void list_append(bool is_long, uint32_t tile, uint32_
     if (is_long) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = tile;
 }
 
+// Timing ablations of the scatter (results WRONG on purpose, never defined in the shipped build): make EXTRA=-DGSR_BIN_ABLATE=n
+//   1: the (depth, id) pairs are not stored   2: no instance is processed at all (prologue: tile starts, ranges, long-list announcements)
+#ifndef GSR_BIN_ABLATE
+#define GSR_BIN_ABLATE 0
+#endif
+
 struct SliceRect {
     uint32_t mnx, mny, mxx, mxy, dbits;
     unsigned long long mask;  // reachable tiles of the rectangle (bit = row-major position); ~0 = all (no culling, or > 64 tiles)
@@ -472,16 +478,17 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_banded_kernel(int 
     }
     if (sidx == 0 && threadIdx.x == 0) { order[GSR_LONG_COUNT(T) + b] = s_nlong[0]; order[GSR_MID_COUNT(T) + b] = s_nlong[1]; }
     if (sidx == 0 && threadIdx.x < 256) order[GSR_CLASS_HIST(T) + b * 256 + threadIdx.x] = s_cls[threadIdx.x];
+    if (GSR_BIN_ABLATE >= 2 && !(have && r.dbits == 0x12345678u)) have = false;  // (keeps the first loads alive)
     while (have) {
         const uint32_t y0 = max(r.mny, row0), y1 = min(r.mxy, row1);
         for (uint32_t y = y0; y < y1; y++)
             for (uint32_t x = r.mnx; x < r.mxx; x++) {
                 if (!r.listed(x, y)) continue;
                 const uint32_t slot = atomicAdd(&s_cur[(y - row0) * (uint32_t)G.gx + x], 1u);
-                bins[slot] = make_uint2(idx, r.dbits);  // little-endian u64 = depth << 32 | id
+                if (GSR_BIN_ABLATE != 1 || slot == 0xFFFFFFFFu) bins[slot] = make_uint2(idx, r.dbits);  // little-endian u64 = depth << 32 | id
             }
         i += SLICE_THREADS;
-        have = i < last;
+        have = i < last && GSR_BIN_ABLATE < 2;
         if (have) {
             idx = band_list[(size_t)b * P + i];
             r = load_rect(splat, (int)idx, G.gx, G.gy, G.cull);
