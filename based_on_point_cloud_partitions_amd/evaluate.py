@@ -38,7 +38,8 @@ def seamless_merge_and_evaluate(block, index, origin_boxes, views, gts, bg, grou
     import torch.distributed as dist
 
     dev = block.device
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # a world-size-1 group still goes through the collectives (the same RCCL entry points an 8-GPU run uses)
+    distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)

@@ -121,7 +121,7 @@ def merge_partitions(block, box, group=None):
     import torch.distributed as dist
 
     kept = block[crop_mask(block[:, :3], box)].contiguous()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return dedup_first_lexicographic(kept)
     allrows, _ = all_gather_blocks(kept, group)  # partition (= rank) order
     return dedup_first_lexicographic(allrows)

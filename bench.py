@@ -18,16 +18,58 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks_if_needed(argv):
+    """`python bench.py --gpus N` from a plain shell (the per-partition launcher of the reference, auto_train.py:22-51, is a loop of
+    `os.system("python train.py ...")`): when N > 1 and no launcher has set RANK, start the N ranks with torch.distributed.run as a
+    FRESH CHILD PROCESS -- before torch is imported here, so this parent never touches a GPU -- hand the child our stdout (rank 0's
+    JSON line arrives unchanged) and exit with its return code."""
+    n = _requested_gpus(argv)
+    if n <= 1 or "RANK" in os.environ:
+        return
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    launch_ranks_if_needed(sys.argv[1:])
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from based_on_point_cloud_partitions_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib  # noqa: E402
 from based_on_point_cloud_partitions_amd import synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PLAIN_CYCLES = 2.4  # SIMD cycles per plain wave64 VOP2/VOP3 instruction with 4-8 waves per SIMD (profiles/r01_valu_cost.txt)
+# the VALU-issue-bound kernels and the mean price-list cycles of one of their VALU instructions (DESIGN.md §5: the mix per blend event)
+VALU_BOUND = {"render_backward": 3.0, "render_forward": 2.6}
 FP32_VALU_PEAK_TFLOPS = 157.3
 
 
@@ -311,6 +353,9 @@ def main():
                     help="memory order of the Gaussians: the workload's own (random, BASELINE.md) or sorted by the Morton code of xyz "
                          "(what a trainer gets by re-ordering its model at densification time; not the headline workload)")
     ap.add_argument("--no-stage-timers", action="store_true", help="time the region without per-stage HIP events")
+    ap.add_argument("--dist", default="auto", choices=["auto", "on", "off"],
+                    help="process group at N = 1: auto = bring up a world-size-1 RCCL group (continue without one if it fails), "
+                         "on = required, off = none; N > 1 always has one")
     ap.add_argument("--spinup-ms", type=float, default=6000.0,
                     help="upper limit of the untimed spin-up before the warm-up: batches of 64 steps run until four in a row bring no "
                          "improvement of 0.5 %% (at least 0.5 s).  A fresh box's GPU reaches its steady clocks only after a second or more of "
@@ -320,24 +365,44 @@ def main():
                     help="also time the step from raw parameters (activations fused or not) and with the L1/SSIM loss (train.py:107-118)")
     args = ap.parse_args()
 
+    # Exactly ONE line may reach stdout (the JSON of rank 0), but libraries write there too (librccl prints a version banner when its
+    # first communicator comes up): file descriptor 1 is pointed at stderr for the whole run and the JSON goes to the saved original.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if world != args.gpus:  # `python bench.py --gpus N` starts its own ranks (launch_ranks_if_needed); this is a launcher with another count
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     ndev = max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU; the modulo only matters for 1-GPU rehearsals
     torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
+    # The collective library: RCCL (torch's "nccl" backend on ROCm).  Two ranks cannot share one GPU under RCCL, so a rehearsal of
+    # N ranks on fewer GPUs falls back to gloo and says so (`collective_backend`).  At N = 1 a world-size-1 RCCL group is brought up
+    # as well (--dist auto): the same librccl init / all_gather_into_tensor / all_reduce / barrier entry points the N > 1 run uses
+    # execute on this GPU, and every `dist` branch below is the one an 8-GPU run takes.
+    dist, dist_error = None, None
+    backend = os.environ.get("GSR_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
+    if args.dist == "on" or world > 1 or (args.dist == "auto" and backend == "nccl"):
+        import datetime
 
-        dist = dist_
-        backend = os.environ.get("GSR_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" for single-GPU rehearsals
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        import torch.distributed as dist_
+        if "RANK" not in os.environ:  # world 1 from a plain shell: be our own rendezvous
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ["MASTER_PORT"] = str(_free_port())
+        try:
+            kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            if backend == "nccl":
+                dist_.init_process_group("nccl", device_id=dev, **kw)
+            else:
+                dist_.init_process_group(backend, **kw)
+            dist = dist_
+        except Exception as exc:  # noqa: BLE001 -- only tolerable at world 1, where no exchange is needed
+            if world > 1 or args.dist == "on":
+                raise
+            dist_error = f"{type(exc).__name__}: {exc}"
     # what the collective library itself saw: every rank contributes its number through one all-gather
     ranks_seen = [0]
     if dist is not None:
@@ -433,6 +498,15 @@ def main():
     _lib.profile_enable(False)
     warm = _lib.profile_collect() if use_timers else {}
     dominant = max(warm, key=lambda k: warm[k][0] / max(warm[k][1], 1)) if any(n for _, n in warm.values()) else "render_backward"
+    # The same K steps timed cold, right behind the W warm-up steps and before any spin-up (`ms_per_step_cold`): what a caller who
+    # just started sees.  They are untimed as far as the headline goes (counted in `untimed_steps`).
+    torch.cuda.synchronize()
+    tc0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    cold_ms = 1e3 * (time.perf_counter() - tc0) / args.steps
+    untimed_steps = args.warmup + args.steps
     # Spin-up (untimed, beyond the W warm-up steps): a GPU that has idled -- a fresh box, but also the tens of milliseconds of host
     # work between two phases of this script -- runs its first ~30 ms of work at lower clocks.  Measured in one process: batches of 64
     # steps settle at 0.700 ms/step, a 48-step region timed right after an idle gap reads 0.735.  So batches of 64 steps run until four in
@@ -456,22 +530,31 @@ def main():
                 break
         spinup = {"steps": k, "ms": round(1e3 * (time.perf_counter() - t_spin), 1), "first_batch_ms_per_step": batches[0],
                   "last_batch_ms_per_step": batches[-1]}
-        if dist is not None:  # ranks leave their spin-up at different times: align, then 32 more steps so that nobody starts cold
+        untimed_steps += k
+        if dist is not None and world > 1:  # ranks leave their spin-up at different times: align, then 32 more steps so that nobody starts cold
             dist.barrier()
             for i in range(32):
                 step(i)
+            untimed_steps += 32
     _lib.profile_enable(use_timers, stages=[dominant])
     gc.disable()
+    # Timed region: K steps between (barrier + device sync) and (device sync + barrier).  Each rank reads its clock right after its own
+    # device sync; the closing barrier follows and `elapsed` becomes the MAX over the ranks of those local times -- from the common
+    # start to the moment the slowest rank's GPU finished.  The closing barrier's own latency (a host round trip through the collective
+    # library, not work of the path) is reported beside it (`closing_barrier_ms`, `ms_per_step_incl_closing_barrier`).
+    tb = time.perf_counter()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    opening_barrier_ms = 1e3 * (t0 - tb)
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_incl_barrier = time.perf_counter() - t0
     gc.enable()
     _lib.profile_enable(False)
     timed = _lib.profile_collect() if use_timers else {}
@@ -486,9 +569,9 @@ def main():
         if timed.get(dominant, (0.0, 0))[1] > 0:
             stage[dominant] = timed[dominant]  # the dominant stage as measured inside the timed region
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([elapsed, elapsed_incl_barrier], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_incl_barrier = (float(v) for v in t.tolist())
 
     # the same steps over the REFERENCE's tile lists (GSR_CULL=0: sort keys, point_list, ranges, n_contrib bit for bit as the
     # reference builds them; the default lists leave out the instances a splat cannot reach) -- reported beside the headline
@@ -590,20 +673,38 @@ def main():
         roofline = None
         if kernels:
             d = kernels[0]
-            roofline = {"kernel": d["kernel"], "bound": "hbm", "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(d["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
-                        "avg_ms": d["avg_ms"], "algorithmic_bytes": int(sb[d["kernel"]]),
-                        "note": "dominant kernel by time; blend kernels are VALU/LDS-bound pair loops (DESIGN.md), so their HBM "
-                                "fraction is low by construction -- see roofline_kernels for the streaming stages and "
-                                "roofline_step for the whole step"}
-            roofline["traffic"] = pmc.get(d["kernel"], {}).get("hbm_bytes")
+            hbm = {"achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["achieved_GBs"] / HBM_PEAK_GBS, 4),
+                   "algorithmic_bytes": int(sb[d["kernel"]]), "traffic": pmc.get(d["kernel"], {}).get("hbm_bytes")}
             # `traffic` (and valu_insts) are NOT measured by this run: they are the PMC passes recorded in the profile file below,
             # attached only because its workload and kernel-source hash equal this run's
-            roofline["traffic_source"] = (f"profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; build {build}, same workload)"
-                                          if roofline["traffic"] is not None else None)
-            for extra in ("valu_insts", "simd_cycles_per_valu_inst"):  # what actually bounds the blend kernels
-                if extra in d:
-                    roofline[extra] = d[extra]
+            src = (f"profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; build {build}, same workload)"
+                   if hbm["traffic"] is not None else None)
+            if d["kernel"] in VALU_BOUND and "valu_insts" in d:
+                # The blend kernels are pair loops limited by VALU instruction issue, not by HBM: the roofline they are
+                # priced against is the chip's VALU issue rate.  `peak` = 1024 SIMDs x 2.4 GHz / 2.4 cycles per plain wave64 VOP
+                # (tools/valu_cost.hip, profiles/r01_valu_cost.txt), `achieved` = VALU wave-instructions retired per second (PMC count
+                # / this run's average launch duration): `frac` is the share of the kernel's SIMD cycles that issuing its VALU
+                # instructions at the PLAIN price needs.  `frac_price_list` prices the kernel's instruction mix (compares / selects /
+                # DPP at 4.3 cycles, v_exp / v_rcp / permlane swaps at 8.5; the mix is the one DESIGN.md §5 derives per blend event).
+                rate = d["valu_insts"] / (d["avg_ms"] * 1e-3) / 1e9
+                peak = 1024 * 2.4 / VALU_PLAIN_CYCLES
+                roofline = {"kernel": d["kernel"], "bound": "valu_issue", "achieved": round(rate, 1), "peak": round(peak, 1),
+                            "unit": "G wave-instr/s", "frac": round(rate / peak, 4),
+                            "frac_price_list": round(rate / peak * VALU_BOUND[d["kernel"]] / VALU_PLAIN_CYCLES, 4),
+                            "mean_cycles_per_inst_price_list": VALU_BOUND[d["kernel"]],
+                            "valu_insts": d["valu_insts"], "simd_cycles_per_valu_inst": d["simd_cycles_per_valu_inst"],
+                            "traffic": hbm["traffic"], "traffic_source": src, "avg_ms": d["avg_ms"], "hbm": hbm,
+                            "note": "dominant kernel by time; VALU-issue-bound pair loop -- its HBM figures are under `hbm` (low by "
+                                    "construction); roofline_kernels has the streaming stages, roofline_step the whole step"}
+            else:
+                roofline = {"kernel": d["kernel"], "bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": hbm["frac"], "traffic": hbm["traffic"], "traffic_source": src, "avg_ms": d["avg_ms"],
+                            "algorithmic_bytes": hbm["algorithmic_bytes"],
+                            "note": ("dominant kernel by time" + ("; a VALU-issue-bound pair loop (DESIGN.md §5) whose instruction count is "
+                                     "not on file for this build (profiles/pmc_traffic.json is from another one): HBM figures only"
+                                     if d["kernel"] in VALU_BOUND else ""))}
+        for k in kernels:
+            k["bound"] = "valu_issue" if k["kernel"] in VALU_BOUND else "hbm"
         fwd_ms = sum(k["avg_ms"] for k in kernels if k["kernel"] in
                      ("preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges", "render_forward"))
         out = {
@@ -621,7 +722,12 @@ def main():
                                "instances_listed_mean": round(float(np.mean([u["listed"] for u in used])), 1),
                                "per_camera": [{"V": u["V"], "R": u["R"], "tile_list_mean": round(u["tile_mean"], 1),
                                                "tile_list_max": u["tile_max"], "listed": u["listed"]} for u in stats]},
-            "spinup": spinup,  # untimed steps before the W warm-up steps (clock ramp of a cold GPU), see --spinup-ms
+            # everything that ran before the timed region: W warm-up steps, the K cold-timed steps, the spin-up (clock ramp of a GPU
+            # that idled, see --spinup-ms) and, at N > 1, the 32 steps behind the aligning barrier
+            "untimed_steps": untimed_steps, "spinup": spinup,
+            "ms_per_step_cold": round(cold_ms, 4),  # the same K steps timed right after the W warm-up steps, no spin-up
+            "ms_per_step_incl_closing_barrier": round(1e3 * elapsed_incl_barrier / args.steps, 4),
+            "closing_barrier_ms": round(1e3 * (elapsed_incl_barrier - elapsed), 3), "opening_barrier_ms": round(opening_barrier_ms, 3),
             "ms_per_step_reference_lists": round(ref_lists_ms, 4) if ref_lists_ms is not None else None,
             "knn_init_ms": knn_ms,
             "knn_points_per_s": round(P / (knn_ms * 1e-3), 1),
@@ -629,7 +735,7 @@ def main():
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(120 * P / 1e9 / (knn_ms * 1e-3) / HBM_PEAK_GBS, 4),
                              "note": "SURVEY.md 8(d): ~120 B per point + data-dependent candidate gathers (L2 / Infinity Cache)"},
             "rccl_world_size": len(ranks_seen), "rccl_ranks_seen": ranks_seen,
-            "collective_backend": (dist.get_backend() if dist is not None else None),
+            "collective_backend": (dist.get_backend() if dist is not None else None), "collective_init_error": dist_error,
             "merge": {"world_size": ev["world_size"], "rows_per_rank_after_crop": ev["counts"], "merged_rows": merged_rows,
                       "merge_allgather_ms": round(ev["merge_allgather_ms"], 3),
                       "allgather_bytes_per_rank": int(max(ev["counts"]) * merge.ROW * 4),
@@ -662,7 +768,7 @@ def main():
                     by[name]["pair_loop"] = {"reference_pair_visits": pairs["pair_visits"], "blended_pairs": pairs["blended_pairs"],
                                              "reference_pair_visits_per_s": round(pairs["pair_visits"] / t, 1),
                                              "fp32_flops_est": int(fl), "fp32_vector_peak_frac": round(fl / t / 157.3e12, 4)}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -8,8 +8,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+RCCL_CHILD = {"proc": None, "out": None}
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # tests/test_rccl_gpu.py needs two other programs run (bench.py starting its own ranks; a world-size-1 RCCL group).  A process
+    # that has initialised the GPU must not start programs on this pool, so the child is started HERE, before anything in this
+    # process touches HIP (device_count() does not), and the test only reads what it wrote.
+    import subprocess
+    import tempfile
+
+    import torch
+
+    expr = getattr(config.option, "markexpr", "") or ""
+    if "not gpu" in expr or "gpu" not in expr or os.environ.get("GSR_NO_RCCL_CHILD") or torch.cuda.device_count() == 0:
+        return
+    out = os.path.join(tempfile.mkdtemp(prefix="gsr_rccl_"), "result.json")
+    log = open(out + ".log", "w")
+    RCCL_CHILD["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_child.py"), out], stdout=log,
+                                          stderr=subprocess.STDOUT)
+    RCCL_CHILD["out"] = out
+
+
+def pytest_unconfigure(config):
+    p = RCCL_CHILD["proc"]
+    if p is not None and p.poll() is None:
+        try:
+            p.wait(timeout=60)
+        except Exception:  # noqa: BLE001
+            p.kill()
 
 
 def pytest_collection_modifyitems(config, items):

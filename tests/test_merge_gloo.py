@@ -165,3 +165,37 @@ def test_partition_layout_of_the_multi_gpu_benchmark():
         kept.append(g.xyz[m])
     allxyz = torch.cat(kept)
     assert torch.unique(allxyz, dim=0).shape[0] == allxyz.shape[0]
+
+
+def test_bench_launcher_starts_the_ranks_as_a_child_process(monkeypatch):
+    """bench.py --gpus N without RANK in the environment: torch.distributed.run as a child, same arguments, 127.0.0.1 rendezvous,
+    return code relayed; with RANK set (a launcher started us) or N = 1 nothing is spawned."""
+    import subprocess
+    import sys
+
+    import bench
+
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks_if_needed(["--gpus", "4", "--steps", "3"])
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert cmd[-5].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen.clear()
+    bench.launch_ranks_if_needed(["--gpus", "1"])
+    bench.launch_ranks_if_needed(["--steps", "3"])
+    monkeypatch.setenv("RANK", "0")
+    bench.launch_ranks_if_needed(["--gpus=4"])
+    assert not seen
