@@ -133,6 +133,89 @@ def ref_projection():
     np.savez_compressed(os.path.join(HERE, "ref_projection.npz"), **out)
 
 
+def ref_cov2d():
+    """The EWA covariance projection (forward.cu:74-113), conic + radius (forward.cu:219-237) and computeCov2DCUDA (backward.cu:144-274)
+    from REFERENCE-derived pieces, all in float64: Sigma from the reference's own build_scaling_rotation / strip_symmetric
+    (utils/general_utils.py:64-103), the view transform from its getWorld2View2, and J as the AUTOGRAD Jacobian of its own projection
+    (utils/graphics_utils.getProjectionMatrix, row-vector convention of scene/cameras.py:109-112, followed by the 0.5 W / 0.5 H of
+    ndc2Pix) -- so neither the analytic Jacobian of forward.cu:89-93 nor any transpose convention of the CUDA code is restated here.
+    cov2D = J W Sigma W^T J^T; + 0.3 on the diagonal; conic = inverse; radius = ceil(3 sqrt(lambda_max)).  Points lie inside the
+    1.3 tan(fov) clamp (the clamp itself is CUDA-only code).  Backward: L = Gx C00 + 2 Gy C01 + Gz C11 (the blend's dL_dconic.y is the
+    gradient per off-diagonal ENTRY, backward.cu:523-526 vs :207-211), differentiated w.r.t. the mean (through J only; Sigma and W are
+    constants there) and w.r.t. the six stored covariance entries (off-diagonals appear twice in Sigma)."""
+    real_zeros = torch.zeros
+    torch.zeros = lambda *a, **k: real_zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        gen = _load("ref_general_utils", "utils/general_utils.py")
+        gu = _load("ref_graphics_utils", "utils/graphics_utils.py")
+        from based_on_point_cloud_partitions_amd import synthetic as syn
+
+        out = {}
+        g = torch.Generator().manual_seed(4711)
+        cams = [(640, 360, 420.0, (5.0, -3.0, 2.5)), (1920, 1080, 1200.0, (0.5, 6.0, 2.0))]
+        for k, (W, H, focal, pos) in enumerate(cams):
+            R, T = syn.look_at_RT(pos)
+            FoVx, FoVy = gu.focal2fov(focal, W), gu.focal2fov(focal, H)
+            wvt = torch.tensor(gu.getWorld2View2(R, T, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1).double()  # cameras.py:109
+            proj = gu.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=FoVx, fovY=FoVy).transpose(0, 1).double()  # cameras.py:110
+            tanx, tany = math.tan(FoVx * 0.5), math.tan(FoVy * 0.5)
+            n = 4000
+            xyz0 = (6.0 * torch.rand(n, 3, generator=g) - 3.0).float()
+            lo, hi = math.log(0.01), math.log(0.3)
+            sc0 = torch.exp(lo + (hi - lo) * torch.rand(n, 3, generator=g)).float()
+            q = torch.randn(n, 4, generator=g)
+            rot0 = (q / q.norm(dim=1, keepdim=True)).float()
+            Gc = torch.randn(n, 3, generator=g).float()
+
+            def evaluate(xyz, cov6):
+                """xyz [P,3], cov6 [P,6] float64 (leaf or not) -> view-space t, cov2D before the filter, conic, lambda_max"""
+                hom = torch.cat((xyz, torch.ones_like(xyz[:, :1])), 1)
+                t = (hom @ wvt)[:, :3]  # geom_transform_points' row-vector convention
+                tl = t.detach().clone().requires_grad_(True) if not t.requires_grad else t
+                th = torch.cat((tl, torch.ones_like(tl[:, :1])), 1) @ proj
+                ndc = th[:, :2] / th[:, 3:4]
+                pix = torch.stack((((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5), 1)  # auxiliary.h:41-44
+                J = torch.stack([torch.autograd.grad(pix[:, i].sum(), tl, create_graph=True)[0] for i in range(2)], 1)  # [P,2,3]
+                c = cov6
+                Sigma = torch.stack((torch.stack((c[:, 0], c[:, 1], c[:, 2]), 1), torch.stack((c[:, 1], c[:, 3], c[:, 4]), 1),
+                                     torch.stack((c[:, 2], c[:, 4], c[:, 5]), 1)), 1)
+                Wr = wvt[:3, :3].transpose(0, 1)  # t = Wr x + wvt[3, :3]
+                M = J @ Wr
+                cov2 = M @ Sigma @ M.transpose(1, 2)
+                covf = cov2 + 0.3 * torch.eye(2, dtype=torch.float64)
+                conic = torch.linalg.inv(covf)
+                lam = torch.linalg.eigvalsh(covf)[:, 1]
+                return t, pix, cov2, conic, lam
+
+            L = gen.build_scaling_rotation(sc0.double(), rot0.double())  # gaussian_model.py:30
+            cov6_all = gen.strip_symmetric(L @ L.transpose(1, 2)).float()  # what the rasterizer is handed as cov3D_precomp (fp32)
+            t, pix, cov2, conic, lam = evaluate(xyz0.double(), cov6_all.double())
+            r3 = 3.0 * torch.sqrt(lam)
+            a, b, c = cov2[:, 0, 0] + 0.3, cov2[:, 0, 1], cov2[:, 1, 1] + 0.3
+            mid = 0.5 * (a + c)
+            keep = ((t[:, 2] > 0.5) & (t[:, 0].abs() < 0.95 * tanx * t[:, 2]) & (t[:, 1].abs() < 0.95 * tany * t[:, 2])
+                    & (mid * mid - (a * c - b * b) > 0.2)                   # forward.cu:226-227: the max(0.1, .) clamp is inactive
+                    & ((r3 - torch.round(r3)).abs() > 1e-3) & (r3 < 200.0)  # ceil() is decided well away from an integer
+                    & (lam / (a * c - b * b) * lam < 400.0)).detach()       # 2D condition number lambda_max / lambda_min < 400
+            idx = torch.nonzero(keep)[:200, 0]
+            assert idx.numel() == 200
+            xyz = xyz0[idx].double().requires_grad_(True)
+            cov6 = cov6_all[idx].double().requires_grad_(True)
+            t, pix, cov2, conic, lam = evaluate(xyz, cov6)
+            Gd = Gc[idx].double()
+            (Gd[:, 0] * conic[:, 0, 0] + 2.0 * Gd[:, 1] * conic[:, 0, 1] + Gd[:, 2] * conic[:, 1, 1]).sum().backward()
+            out.update({f"cam{k}": np.array([W, H, focal, *pos]), f"xyz{k}": xyz0[idx].numpy(), f"cov6_{k}": cov6_all[idx].numpy(),
+                        f"scales{k}": sc0[idx].numpy(), f"rotations{k}": rot0[idx].numpy(), f"G{k}": Gc[idx].numpy(),
+                        f"cov2d{k}": torch.stack((cov2[:, 0, 0], cov2[:, 0, 1], cov2[:, 1, 1]), 1).detach().numpy(),
+                        f"conic{k}": torch.stack((conic[:, 0, 0], conic[:, 0, 1], conic[:, 1, 1]), 1).detach().numpy(),
+                        f"radius{k}": torch.ceil(3.0 * torch.sqrt(lam)).detach().numpy().astype(np.int32),
+                        f"pix{k}": pix.detach().numpy(), f"dxyz{k}": xyz.grad.numpy(), f"dcov6_{k}": cov6.grad.numpy()})
+        out["n"] = np.array(len(cams))
+        np.savez_compressed(os.path.join(HERE, "ref_cov2d.npz"), **out)
+    finally:
+        torch.zeros = real_zeros
+
+
 def ref_cameras():
     gu = _load("ref_graphics_utils", "utils/graphics_utils.py")
     from based_on_point_cloud_partitions_amd import synthetic as syn
@@ -304,6 +387,7 @@ if __name__ == "__main__":
     ref_sh_grad()
     ref_cov3d()
     ref_projection()
+    ref_cov2d()
     ref_cameras()
     ref_loss()
     ref_loss_decoupled()
