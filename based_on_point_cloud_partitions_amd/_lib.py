@@ -8,8 +8,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 14
+# GSR_LIBRARY selects another build of the same library (tools/build_ab.sh: A/B variants live in their own directory, the
+# shipped .so is never rebuilt in place); gsr_build_info() says what a loaded binary was built with.
+SO_PATH = os.environ.get("GSR_LIBRARY") or os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
+ABI_VERSION = 15
 
 _lib = None
 
@@ -71,6 +73,8 @@ PROTOTYPES = {
     "gsr_knn_scratch_bytes": (c_size, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),
+    "gsr_debug_capture_sums": (c_int, [c_void_p]),
+    "gsr_build_info": (ctypes.c_char_p, []),
     "gsr_set_variant": (c_int, [ctypes.c_char_p, c_int]),
     "gsr_get_variant": (c_int, [ctypes.c_char_p, c_int]),
     "gsr_profile_enable": (None, [c_int]),
@@ -132,6 +136,17 @@ def profile_collect():
     cnt = (c_i64 * n)()
     check(load().gsr_profile_collect(ms, cnt, n), "gsr_profile_collect")
     return {STAGES[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+
+def build_info():
+    """gsr_build_info(): ABI version, the two compile-time ablation macros (0 in a shipped build) and make's EXTRA flags."""
+    return load().gsr_build_info().decode()
+
+
+def capture_sums(tensor):
+    """Test hook (two-stage gradient check): while set, every backward also stores the per-Gaussian blend sums its chain consumes
+    into `tensor` ([P,12] float32 on the device); None switches it off."""
+    check(load().gsr_debug_capture_sums(None if tensor is None else tensor.data_ptr()), "gsr_debug_capture_sums")
 
 
 def set_variant(name, value):

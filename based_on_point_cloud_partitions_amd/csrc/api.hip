@@ -13,6 +13,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+float* g_capture_sums = nullptr;  // gsr_debug_capture_sums
 
 int fail(int code, const char* fmt, const char* a = "")
 {
@@ -95,8 +96,9 @@ bool mailbox_acquire(unsigned long long** host_slot, unsigned long long** dev_sl
 // Waits for the tagged value.  Every 2^17 spins (~a millisecond) the stream is queried: if it has drained (hipSuccess) without the word
 // showing up, or reports an error (a faulted kernel), the wait ends at once and the caller falls back to memcpy + stream
 // synchronisation, which surfaces the error -- a dead kernel stalls the host for a millisecond, not for seconds.
-bool mailbox_wait(const unsigned long long* host_slot, uint32_t seq, uint32_t* value, hipStream_t s)
+bool mailbox_wait(const unsigned long long* host_slot, uint32_t seq, uint32_t* value, hipStream_t s, hipError_t* stream_error)
 {
+    *stream_error = hipSuccess;
     const volatile unsigned long long* p = host_slot;
     for (long spin = 0; spin < 400000000L; spin++) {
         const unsigned long long v = *p;
@@ -107,7 +109,7 @@ bool mailbox_wait(const unsigned long long* host_slot, uint32_t seq, uint32_t* v
             if (q != hipErrorNotReady) {  // drained or failed: one last look at the word, then give up
                 const unsigned long long v2 = *p;
                 if (q == hipSuccess && (uint32_t)(v2 >> 32) == seq) { *value = (uint32_t)v2; return true; }
-                if (q != hipSuccess) (void)hipGetLastError();
+                if (q != hipSuccess) *stream_error = q;  // handed to the caller: a failed launch must not end as a stale R with status 0
                 return false;
             }
         }
@@ -238,7 +240,9 @@ static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_byte
 static int wait_geometry(const GeometryWait& w, int64_t* num_rendered_host, hipStream_t s)
 {
     uint32_t total = 0;
-    if (!w.mail || !mailbox_wait(w.mail_host, w.seq, &total, s)) {
+    hipError_t qe = hipSuccess;
+    if (!w.mail || !mailbox_wait(w.mail_host, w.seq, &total, s, &qe)) {
+        if (qe != hipSuccess) { (void)hipGetLastError(); return fail(-100, "forward_geometry: %s", hipGetErrorString(qe)); }
         hipError_t e = hipMemcpyAsync(&total, w.total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(-100, "forward_geometry: %s", hipGetErrorString(e));
@@ -498,6 +502,7 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     a.point_offsets = (const uint32_t*)(g + G.point_offsets);
     a.row_offsets = (const uint32_t*)(g + G.row_offsets);
     a.grad_rows = (const float*)scratch;
+    a.sums_out = g_capture_sums;
     { StageTimer t(GSR_STAGE_GAUSS_BWD, s); gsr_launch_gaussian_backward(a, s); }
     return check_hip("backward");
 }
@@ -815,6 +820,23 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
         if (n_contrib) hipMemcpyAsync(n_contrib, im + I.n_contrib, N * 4, hipMemcpyDeviceToDevice, s);
     }
     return check_hip("debug_export");
+}
+
+int gsr_debug_capture_sums(float* sums)
+{
+    g_capture_sums = sums;
+    return 0;
+}
+
+const char* gsr_build_info(void)
+{
+#ifndef GSR_EXTRA_FLAGS
+#define GSR_EXTRA_FLAGS ""
+#endif
+    static char info[256];
+    snprintf(info, sizeof(info), "abi=%d ablate=%d bin_ablate=%d extra=[%s]", GSR_ABI_VERSION, gsr_render_backward_ablate(),
+             gsr_binning_ablate(), GSR_EXTRA_FLAGS);
+    return info;
 }
 
 void gsr_profile_enable(int on)

@@ -1003,3 +1003,5 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
     hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, nbl, seg, order, ranges,
                        reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
 }
+
+int gsr_binning_ablate() { return GSR_BIN_ABLATE; }

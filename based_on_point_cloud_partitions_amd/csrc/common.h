@@ -210,8 +210,11 @@ struct GaussBackwardArgs {
     int raw;
     const float *features_dc, *features_rest;
     float *dL_dfeatures_dc, *dL_dfeatures_rest;
+    float* sums_out;  // test hook (gsr_debug_capture_sums): the nine reduced blend sums per Gaussian, [P][GSR_GROW_F], or NULL
 };
 void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s);
+int gsr_render_backward_ablate();  // the compile-time timing ablations of the two kernels (0 in every shipped build)
+int gsr_binning_ablate();
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 size_t gsr_appearance_layout(int H, int W, size_t* dz2_off, size_t* du_off, size_t* p3_off, size_t* p2_off);

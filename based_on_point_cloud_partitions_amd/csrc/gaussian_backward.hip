@@ -34,6 +34,7 @@ struct GaussBackwardPtrs {
     float* __restrict__ dL_drots;
     const float* __restrict__ features_dc; const float* __restrict__ features_rest;
     float* __restrict__ dL_dfeatures_dc; float* __restrict__ dL_dfeatures_rest;
+    float* __restrict__ sums_out;
     int P, D, M, has_shs, has_scales, lds_floats;
     float scale_modifier, tan_fovx, tan_fovy;
 };
@@ -152,6 +153,11 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     const float dL_dmean2D_x = g[GR_MX], dL_dmean2D_y = g[GR_MY];
     const float dLc_x = g[GR_CX], dLc_y = g[GR_CY], dLc_w = g[GR_CW];
     float dL_dcol[3] = {g[GR_R], g[GR_G], g[GR_B]};
+    if (a.sums_out) {  // test hook: exactly the sums the chain below consumes
+        float* so = a.sums_out + (size_t)idx * GSR_GROW_F;
+#pragma unroll
+        for (int i = 0; i < 9; i++) so[i] = g[i];
+    }
     o_m2[0] = dL_dmean2D_x; o_m2[1] = dL_dmean2D_y; o_m2[2] = 0.f;
     if (!RAW || a.dL_dcolors) { o_col[0] = dL_dcol[0]; o_col[1] = dL_dcol[1]; o_col[2] = dL_dcol[2]; }
     if (RAW) {  // d sigmoid: y (1 - y), y = the activated opacity kept in the splat record
@@ -476,6 +482,7 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscales = a.dL_dscales; p.dL_drots = a.dL_drots;
     p.features_dc = a.features_dc; p.features_rest = a.features_rest;
     p.dL_dfeatures_dc = a.dL_dfeatures_dc; p.dL_dfeatures_rest = a.dL_dfeatures_rest;
+    p.sums_out = a.sums_out;
     p.P = a.P; p.D = a.D; p.M = a.M; p.has_shs = a.has_shs; p.has_scales = a.has_scales;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     const int bs = gsr_variant("GB_BLOCK", 128);

@@ -456,3 +456,5 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
     else { if (fast) GSR_BWD_LAUNCH(1, true); else GSR_BWD_LAUNCH(1, false); }
 #undef GSR_BWD_LAUNCH
 }
+
+int gsr_render_backward_ablate() { return GSR_ABLATE; }

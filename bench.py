@@ -651,7 +651,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             meta = pmc.pop("_meta", {})
-            if meta.get("workload") != workload or meta.get("build") != build:
+            if meta.get("workload") != workload or meta.get("build") != build or not _lib.build_info().endswith(" ablate=0 bin_ablate=0 extra=[]"):
                 pmc_stale = {"source": "profiles/pmc_traffic.json", "measured_on": meta,
                              "hbm_bytes": {k: v.get("hbm_bytes") for k, v in pmc.items()},
                              "valu_insts": {k: v.get("sq_insts_valu") for k, v in pmc.items() if "sq_insts_valu" in v}}
@@ -712,7 +712,7 @@ def main():
             "value": round(world * args.steps / elapsed, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "build": build,
+            "build": build, "build_info": _lib.build_info(),
             "config": {"workload": workload + ("" if args.order == "as-generated" else f" [Gaussians in {args.order} order]"), "gaussians_per_gpu": P,
                        "image": [W, H], "sh_degree": 3, "parallelism": f"{world} independent partition(s), 1 per GPU"},
             "workload_stats": {"P": P, "V_mean": round(V, 1), "R_mean": round(R, 1), "N": N, "key_bits": key_bits,

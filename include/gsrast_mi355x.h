@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 14
+#define GSR_ABI_VERSION 15
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -210,6 +210,17 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
                      const void* image_buffer, float* means2D, float* depths, float* conic_opacity, float* rgb, float* cov3D,
                      uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_offsets, uint64_t* keys_sorted,
                      uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, void* stream);
+
+/* Test hook for the two-stage gradient check (tests/helpers.py): while `sums` is non-NULL every gsr_backward / gsr_backward_params
+ * call of this process also stores, per visible Gaussian, the nine blend-level sums its per-Gaussian chain consumes -- rows of 12
+ * floats [P][12]: dL_dmean2D.xy, dL_dconic.xyw, dL_dopacity, dL_dcolor.rgb (the reference keeps them in dL_dmean2D / dL_dconic /
+ * dL_dopacity / dL_dcolor, rasterize_points.cu:151-159); rows of culled Gaussians are not written.  NULL switches it off. */
+int gsr_debug_capture_sums(float* sums);
+
+/* What this binary was built with: "abi=<n> ablate=<GSR_ABLATE> bin_ablate=<GSR_BIN_ABLATE> extra=[<make EXTRA=...>]".  The two
+ * ablation macros are timing experiments that produce wrong results on purpose; a shipped library reports 0 for both and an
+ * empty extra (tests/test_abi.py checks the built .so; bench.py prints the string). */
+const char* gsr_build_info(void);
 
 /* Overrides an experiment switch (environment GSR_<NAME>) for this process: A/B measurements and the tests
  * that keep the alternative kernels covered.  No switch changes a result beyond the documented tolerances.

@@ -927,78 +927,6 @@ void orc_preprocess_backward(int P, int D, int M, const float* means3D, const in
     }
 }
 
-/* Condition numbers of the per-Gaussian chain above, for the tests' gradient tolerance (NOT a reference function).
- * Inputs per Gaussian: x = the eight blend sums the chain consumes (dL_dmean2D.xy, dL_dconic.xyw, dL_dcolor.rgb) and
- * S = the sums of the magnitudes of their terms (orc_render_backward_abs).  Outputs per chain output element:
- *   cond  = sum_k |chain(S_k e_k)|: the chain is linear in x, so this is |Jacobian| . S -- how far an error of the sums,
- *           each bounded by ~eps_sum * S_k, can move the output;
- *   noise = max over `trials` evaluations of |chain(x + u * rel * S) - chain(x)|, u uniform in [-1, 1] per sum: the sums are
- *           only determined up to ~rel * S (any fp32 summation order, the reference's own float atomics included), and the
- *           chain is evaluated in fp32 with intermediates that can be orders of magnitude larger than its results (1 / det^2
- *           of a nearly singular 2D covariance: the three columns of the conic -> covariance map cancel 1000 : 1 for a
- *           needle), so its result is a STEP function of its inputs there -- a few ulps of input flip an intermediate's
- *           last bit and move the result by eps * |intermediate|.  This is the scatter of the reference's own results over
- *           its input uncertainty, sampled; it reduces to |Jacobian| . (rel S) <= rel * cond where the chain is well behaved.
- * Layout of cond / noise: [P][3 + 6 + 3M + 3 + 4] = means3D, cov3D, sh, scales, rotations. */
-void orc_chain_condition(int P, int D, int M, const float* means3D, const int* radii, const float* shs,
-                         const uint8_t* clamped, const float* scales, const float* rotations, float scale_modifier,
-                         const float* cov3Ds, const float* viewmatrix, const float* projmatrix, int W, int H,
-                         float tan_fovx, float tan_fovy, const float* campos,
-                         const float* x_mean2D, const float* x_conic, const float* x_color,
-                         const float* S_mean2D, const float* S_conic, const float* S_color, int trials, float rel,
-                         float* cond, float* noise)
-{
-    const int NO = 3 + 6 + 3 * M + 3 + 4;
-#pragma omp parallel for schedule(static)
-    for (int idx = 0; idx < P; idx++) {
-        float* c_out = cond + (size_t)idx * NO;
-        float* n_out = noise + (size_t)idx * NO;
-        for (int j = 0; j < NO; j++) { c_out[j] = 0.f; n_out[j] = 0.f; }
-        if (!(radii[idx] > 0)) continue;
-        float base[16 + 3 * 16], cur[16 + 3 * 16];
-        float in[10]; /* m2d[3], conic[4], color[3] */
-        const float* sh_i = shs ? shs + (size_t)idx * M * 3 : NULL;
-        const float* sc_i = scales ? scales + 3 * (size_t)idx : NULL;
-        const float* rot_i = rotations ? rotations + 4 * (size_t)idx : NULL;
-#define RUN(dst)                                                                                                              \
-        do {                                                                                                                  \
-            for (int j = 0; j < NO; j++) (dst)[j] = 0.f;                                                                      \
-            preprocess_backward_one(0, D, M, means3D + 3 * (size_t)idx, sh_i, clamped + 3 * (size_t)idx, sc_i, rot_i,         \
-                                    scale_modifier, cov3Ds + 6 * (size_t)idx, viewmatrix, projmatrix, W, H, tan_fovx,        \
-                                    tan_fovy, campos, in, in + 3, (dst), in + 7, (dst) + 3, (dst) + 9, (dst) + 9 + 3 * M,    \
-                                    (dst) + 12 + 3 * M);                                                                      \
-        } while (0)
-        const float xs[8] = {x_mean2D[3 * idx], x_mean2D[3 * idx + 1], x_conic[4 * idx], x_conic[4 * idx + 1], x_conic[4 * idx + 3],
-                             x_color[3 * idx], x_color[3 * idx + 1], x_color[3 * idx + 2]};
-        const float Ss[8] = {S_mean2D[3 * idx], S_mean2D[3 * idx + 1], S_conic[4 * idx], S_conic[4 * idx + 1], S_conic[4 * idx + 3],
-                             S_color[3 * idx], S_color[3 * idx + 1], S_color[3 * idx + 2]};
-        static const int slot[8] = {0, 1, 3, 4, 6, 7, 8, 9};
-        for (int k = 0; k < 8; k++) {
-            for (int j = 0; j < 10; j++) in[j] = 0.f;
-            in[slot[k]] = Ss[k];
-            RUN(cur);
-            for (int j = 0; j < NO; j++) c_out[j] += fabsf(cur[j]);
-        }
-        for (int j = 0; j < 10; j++) in[j] = 0.f;
-        for (int k = 0; k < 8; k++) in[slot[k]] = xs[k];
-        RUN(base);
-        uint32_t rng = 2654435761u * (uint32_t)(idx + 1);
-        for (int t = 0; t < trials; t++) {
-            for (int k = 0; k < 8; k++) {
-                rng = rng * 1664525u + 1013904223u;
-                const float u = (float)((rng >> 8) & 0xFFFFu) * (1.0f / 32768.0f) - 1.0f;
-                in[slot[k]] = xs[k] + u * (rel * Ss[k]);
-            }
-            RUN(cur);
-            for (int j = 0; j < NO; j++) {
-                const float d = fabsf(cur[j] - base[j]);
-                if (d > n_out[j]) n_out[j] = d;
-            }
-        }
-#undef RUN
-    }
-}
-
 /* Stand-alone entry points for the pieces of K1 / K10 that the reference's own PYTHON can pin (tests/golden/ref_cov3d.npz,
  * ref_sh_grad.npz): computeCov3D (forward.cu:118-152) and its backward (backward.cu:278-341) for a batch, and the SH colour
  * backward (backward.cu:20-139) alone -- dL/dSH and the part of dL/dmean that flows through the view direction. */

@@ -144,27 +144,36 @@ def block_flags(st):
     return flags[:R]
 
 
-def backward(st, dL_dpix):
-    """Full backward (K8..K10) for a state returned by forward()."""
+def blend_backward(st, dL_dpix, abs_terms=False):
+    """K8 alone: the per-Gaussian blend-level sums dL_dmeans2D [P,3], dL_dconic [P,4] (x, y, -, w), dL_dopacity [P,1],
+    dL_dcolors [P,3] of a state returned by forward(), accumulated in double.  abs_terms=True: the same sums with every term
+    replaced by its magnitude (orc_render_backward_abs) -- the condition number of each sum for the tests' tolerance."""
     L = lib()
-    P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
+    P, W, H = st["P"], st["W"], st["H"]
     inp = st["_inputs"]
     dL_dpix = _f32(dL_dpix).reshape(3, H, W)
-    g = dict(
-        dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
-        dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolors=np.zeros((P, 3), np.float32),
-        dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
-        dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
-        dL_drotations=np.zeros((P, 4), np.float32))
+    g = dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
+             dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolors=np.zeros((P, 3), np.float32))
     if P == 0:
         return g
     colors = inp["colors_precomp"] if inp["colors_precomp"] is not None else st["rgb"]
-    cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else st["cov3D"]
-    L.orc_render_backward(ctypes.c_int(P), ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32),
-                          _p(st["point_list"], _u32), _p(inp["bg"], _f), _p(st["means2D"], _f),
-                          _p(st["conic_opacity"], _f), _p(colors, _f), _p(st["final_T"], _f), _p(st["n_contrib"], _u32),
-                          _p(dL_dpix, _f), _p(g["dL_dmeans2D"], _f), _p(g["dL_dconic"], _f), _p(g["dL_dopacity"], _f),
-                          _p(g["dL_dcolors"], _f))
+    fn = L.orc_render_backward_abs if abs_terms else L.orc_render_backward
+    fn(ctypes.c_int(P), ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32), _p(st["point_list"], _u32), _p(inp["bg"], _f),
+       _p(st["means2D"], _f), _p(st["conic_opacity"], _f), _p(colors, _f), _p(st["final_T"], _f), _p(st["n_contrib"], _u32),
+       _p(dL_dpix, _f), _p(g["dL_dmeans2D"], _f), _p(g["dL_dconic"], _f), _p(g["dL_dopacity"], _f), _p(g["dL_dcolors"], _f))
+    return g
+
+
+def backward(st, dL_dpix):
+    """Full backward (K8..K10) for a state returned by forward()."""
+    M = st["M"]
+    P = st["P"]
+    g = blend_backward(st, dL_dpix)
+    if P == 0:
+        g.update(dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
+                 dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
+                 dL_drotations=np.zeros((P, 4), np.float32))
+        return g
     return chain_backward(st, g)
 
 
@@ -189,57 +198,6 @@ def chain_backward(st, g):
         _p(g["dL_dmeans2D"], _f), _p(g["dL_dconic"], _f), _p(g["dL_dmeans3D"], _f), _p(g["dL_dcolors"], _f),
         _p(g["dL_dcov3D"], _f), _p(g["dL_dsh"], _f), _p(g["dL_dscales"], _f), _p(g["dL_drotations"], _f))
     return g
-
-
-def backward_condition(st, dL_dpix, trials=16, rel=2e-6):
-    """Computed condition numbers of backward(), element by element, for the tests' gradient tolerance.
-    cond[name]: an upper bound on the sum of the magnitudes of the terms that any summation order adds up to the element --
-    blend-level sums (means2D, colours, opacity, conic) from orc_render_backward_abs; for the outputs of the per-Gaussian chain
-    behind them (K9 + K10, linear in those sums) sum_k |column k of its Jacobian| * S_k (orc_chain_condition).
-    cond["noise:" + name] (chain outputs only): max over `trials` random perturbations of the sums within +-rel * S of
-    |chain(perturbed) - chain(sums)| -- the scatter of the chain's own fp32 evaluation over the uncertainty every fp32
-    summation order (the reference's float atomics included) leaves in its inputs.  Where the chain is well behaved this is
-    <= rel * cond (the linear response), and only the EXCESS over that is returned: zero for well-conditioned elements; for
-    nearly singular 2D covariances (needle-shaped splats) the fp32 chain is a step function of its inputs and the scatter is
-    orders of magnitude larger (oracle/gs_oracle.c, orc_chain_condition)."""
-    L = lib()
-    P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
-    inp = st["_inputs"]
-    dL_dpix = _f32(dL_dpix).reshape(3, H, W)
-    mk = lambda: dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
-                      dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolors=np.zeros((P, 3), np.float32))
-    S, x = mk(), mk()
-    shapes = (("dL_dmeans3D", (P, 3)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)), ("dL_drotations", (P, 4)))
-    cond = dict(S)
-    if P == 0:
-        for k, shape in shapes:
-            cond[k] = np.zeros(shape, np.float32)
-            cond["noise:" + k] = np.zeros(shape, np.float32)
-        return cond
-    colors = inp["colors_precomp"] if inp["colors_precomp"] is not None else st["rgb"]
-    cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else st["cov3D"]
-    for fn, dst in ((L.orc_render_backward_abs, S), (L.orc_render_backward, x)):
-        fn(ctypes.c_int(P), ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32), _p(st["point_list"], _u32), _p(inp["bg"], _f),
-           _p(st["means2D"], _f), _p(st["conic_opacity"], _f), _p(colors, _f), _p(st["final_T"], _f), _p(st["n_contrib"], _u32),
-           _p(dL_dpix, _f), _p(dst["dL_dmeans2D"], _f), _p(dst["dL_dconic"], _f), _p(dst["dL_dopacity"], _f), _p(dst["dL_dcolors"], _f))
-    NO = 16 + 3 * M
-    c = np.zeros((P, NO), np.float32)
-    n = np.zeros((P, NO), np.float32)
-    L.orc_chain_condition(
-        ctypes.c_int(P), ctypes.c_int(D), ctypes.c_int(M), _p(inp["means3D"], _f), _p(st["radii"], _i), _p(inp["shs"], _f),
-        _p(st["clamped"], _u8), _p(inp["scales"], _f), _p(inp["rotations"], _f), ctypes.c_float(inp["scale_modifier"]),
-        _p(cov3D, _f), _p(inp["vm"], _f), _p(inp["pm"], _f), ctypes.c_int(W), ctypes.c_int(H), ctypes.c_float(inp["tanfovx"]),
-        ctypes.c_float(inp["tanfovy"]), _p(inp["cp"], _f), _p(x["dL_dmeans2D"], _f), _p(x["dL_dconic"], _f), _p(x["dL_dcolors"], _f),
-        _p(S["dL_dmeans2D"], _f), _p(S["dL_dconic"], _f), _p(S["dL_dcolors"], _f), ctypes.c_int(trials), ctypes.c_float(rel), _p(c, _f), _p(n, _f))
-    o = 0
-    for k, shape in (("dL_dmeans3D", (P, 3)), ("dL_dcov3D", (P, 6)), ("dL_dsh", (P, M, 3)), ("dL_dscales", (P, 3)),
-                     ("dL_drotations", (P, 4))):
-        w = int(np.prod(shape[1:]))
-        cond[k] = np.ascontiguousarray(c[:, o:o + w]).reshape(shape)
-        # only what exceeds the linear response rel * cond (already covered by the cond term of the tolerance) is reported
-        cond["noise:" + k] = np.maximum(np.ascontiguousarray(n[:, o:o + w]).reshape(shape) - np.float32(rel) * cond[k], 0)
-        o += w
-    return cond
 
 
 def cov3d(scales, rotations, scale_modifier=1.0):

@@ -83,18 +83,29 @@ def hip_forward_raw(g, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, scale_modifier=1.0,
     return ctx
 
 
-def hip_backward_raw(ctx, dL_dpix):
+def hip_backward_raw(ctx, dL_dpix, capture=False):
+    """gsr_backward through the operator's backward entry.  capture=True also returns, under "sums", the [P,12] per-Gaussian blend
+    sums the kernel's own chain consumed (gsr_debug_capture_sums) -- the input of the second stage of the gradient check."""
+    from based_on_point_cloud_partitions_amd import _lib
     from based_on_point_cloud_partitions_amd import rasterizer as rz
 
     st = ctx["st"]
     dL = torch.as_tensor(dL_dpix, dtype=torch.float32).to(ctx["means3D"].device)
-    out = rz.rasterize_gaussians_backward(
-        st.bg, ctx["means3D"], ctx["radii"], ctx["colors"], ctx["scales"], ctx["rots"], ctx["scale_modifier"], ctx["cov"],
-        st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, dL, ctx["sh"], ctx["sh_degree"], st.campos, ctx["gb"], ctx["R"],
-        ctx["bb"], ctx["ib"], False)
-    torch.cuda.synchronize()
+    sums = torch.zeros(ctx["means3D"].shape[0], 12, device=dL.device) if capture else None
+    _lib.capture_sums(sums)
+    try:
+        out = rz.rasterize_gaussians_backward(
+            st.bg, ctx["means3D"], ctx["radii"], ctx["colors"], ctx["scales"], ctx["rots"], ctx["scale_modifier"], ctx["cov"],
+            st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, dL, ctx["sh"], ctx["sh_degree"], st.campos, ctx["gb"], ctx["R"],
+            ctx["bb"], ctx["ib"], False)
+        torch.cuda.synchronize()
+    finally:
+        _lib.capture_sums(None)
     names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
-    return {k: v.cpu().numpy() for k, v in zip(names, out)}
+    res = {k: v.cpu().numpy() for k, v in zip(names, out)}
+    if capture:
+        res["sums"] = sums.cpu().numpy()
+    return res
 
 
 def reference_lists():
@@ -174,76 +185,107 @@ def _assert_culled_lists(ex, st):
     assert kept_total == int(got_rg[:, 1].max(initial=0))  # the culled ranges are contiguous: they end at the number of kept entries
 
 
-# Gradient bar (BASELINE.json north_star: "within 1e-4 abs on rendered RGB/grad"), ELEMENT-WISE against the oracle, whose blend sums
-# are accumulated in double:   |got - want| <= GRAD_ATOL + GRAD_RTOL * |want| + GRAD_COND * cond + GRAD_NOISE * noise
-# `cond` and `noise` are computed for that very element (oracle.backward_condition):
-#  - cond: the sum of the magnitudes of the terms any summation order adds up to it, pushed through the magnitudes of the
-#    per-Gaussian chain's Jacobian.  The HIP kernels sum in fp32 (a 64-lane tree, 4 waves, then a Gaussian's tiles in order) over
-#    terms whose factors carry the hardware v_exp / v_rcp (<= 1e-6 relative): their result may differ from a double sum by
-#    ~2e-6 * sum|terms| whatever the order -- 4e-6 * cond;
-#  - noise (outputs of the per-Gaussian chain only): by how much the largest move of the chain's own fp32 result, over 16 random
-#    perturbations of its input sums within +-2e-6 * sum|terms| (that same uncertainty), EXCEEDS the linear response 2e-6 * cond.
-#    Zero where the chain is well behaved.  Where its intermediates dwarf its results (1/det^2 of a nearly singular 2D covariance:
-#    needle-shaped splats) the fp32 chain is a step function of its inputs, and this is the run-to-run scatter the reference's
-#    own order-dependent atomics produce -- 3x the maximum of 16 samples bounds one more sample.
-# On the benchmark scene the cond term exceeds the first two for a few per cent of the elements and the noise term is non-zero for
-# well under one per cent; no per-tensor scale, no blanket exception.
+# Gradient bar (BASELINE.json north_star: "within 1e-4 abs on rendered RGB/grad"), ELEMENT-WISE and in TWO STAGES (round 4; the
+# one-stage bar of round 3 needed a `noise` term sampled from the oracle's own fp32 chain, i.e. it certified "within the oracle's own
+# instability" on needle-shaped splats):
+#   stage 1, the blend backward (K8): the nine per-Gaussian sums the HIP kernels reduce -- dL_dmean2D.xy, dL_dconic.xyw, dL_dopacity,
+#     dL_dcolor.rgb; the conic sums are read through gsr_debug_capture_sums, the others are outputs -- against the oracle's sums
+#     accumulated in double:      |got - want| <= GRAD_ATOL + GRAD_RTOL * |want| + GRAD_COND * cond
+#     cond = the sum of the magnitudes of the element's terms (orc_render_backward_abs).  The HIP kernels sum in fp32 (a 64-lane tree,
+#     the waves of a tile, then a Gaussian's tiles in order) over terms whose factors carry the hardware v_exp / v_rcp (<= 1e-6
+#     relative), so their result may differ from a double sum by ~2e-6 * sum|terms| whatever the order;
+#   stage 2, the per-Gaussian chain (K9 + K10: conic -> cov2D -> cov3D -> scale / rotation, mean projection, SH): the HIP outputs
+#     against oracle.chain_backward evaluated ON THE HIP KERNEL'S OWN SUMS.  Same inputs, same fp32 expression order, no FMA contraction
+#     on either side: the only differences are the last-bit ones of division / sqrt sequences, so the bar is tight and needs no
+#     conditioning term even for 500:1 needles:     |got - want| <= CHAIN_RTOL * (|want| + largest |want| of that Gaussian's tensor row)
+# No per-tensor scale, no blanket exception, no noise term.
 GRAD_ATOL = 1e-4
 GRAD_RTOL = 1e-4
 GRAD_COND = 4e-6
-GRAD_NOISE = 3.0
+CHAIN_RTOL = 1e-5
 GRAD_TOL = GRAD_ATOL
+BLEND_KEYS = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors")
+CHAIN_KEYS = ("dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
 
 
-def assert_grads_close(got, want, cond, atol=GRAD_ATOL, rtol=GRAD_RTOL, ccoef=GRAD_COND, ncoef=GRAD_NOISE):
-    """Element-wise bar above.  `cond`: dict with the same keys plus optional "noise:<key>" (oracle.backward_condition /
-    raw_condition).  Returns {tensor: worst |err| / tolerance}."""
-    worst = {}
+def unpack_sums(sums12):
+    """[P,12] rows of gsr_debug_capture_sums -> the oracle's blend-sum tensors (dL_dmeans2D [P,3], dL_dconic [P,4] = x, y, -, w, ...)."""
+    s = np.asarray(sums12, np.float32)
+    z = np.zeros(s.shape[0], np.float32)
+    return dict(dL_dmeans2D=np.stack([s[:, 0], s[:, 1], z], 1), dL_dconic=np.stack([s[:, 2], s[:, 3], z, s[:, 4]], 1),
+                dL_dopacity=np.ascontiguousarray(s[:, 5:6]), dL_dcolors=np.ascontiguousarray(s[:, 6:9]))
+
+
+def _bar_stats(a, b, tol):
+    """-> (worst |err| / tol, stats) for one tensor; raises through the caller's assert."""
+    a, b, tol = a.astype(np.float64).reshape(-1), b.astype(np.float64).reshape(-1), np.asarray(tol, np.float64).reshape(-1)
+    assert np.array_equal(np.isfinite(a), np.isfinite(b)), "non-finite values differ"
+    fin = np.isfinite(b)
+    err = np.abs(a[fin] - b[fin])
+    ratio = err / tol[fin]
+    i = int(np.argmax(ratio)) if ratio.size else 0
+    st = dict(max_abs_err=float(err.max()) if err.size else 0.0, worst_ratio=float(ratio[i]) if ratio.size else 0.0,
+              frac_within_1e_4_abs=float(np.mean(err <= 1e-4)) if err.size else 1.0, n=int(err.size),
+              outside=int((ratio > 1).sum()), worst=(float(err[i]), float(tol[fin][i]), float(b[fin][i])) if ratio.size else None)
+    return st
+
+
+def assert_blend_sums_close(got, want, cond, atol=GRAD_ATOL, rtol=GRAD_RTOL, ccoef=GRAD_COND):
+    """Stage 1: `got` / `want` / `cond` dicts over (a subset of) BLEND_KEYS.  Returns {tensor: stats}."""
+    out = {}
     for k in got:
-        a, b = got[k].astype(np.float64).reshape(-1), want[k].astype(np.float64).reshape(-1)
-        if a.size == 0:
+        if got[k].size == 0:
             continue
-        c = np.asarray(cond[k], np.float64).reshape(-1)
-        nz = np.asarray(cond["noise:" + k], np.float64).reshape(-1) if "noise:" + k in cond else np.zeros_like(c)
-        assert a.shape == b.shape == c.shape == nz.shape, (k, a.shape, b.shape, c.shape, nz.shape)
-        assert np.array_equal(np.isfinite(a), np.isfinite(b)), f"{k}: non-finite values differ"
-        fin = np.isfinite(b)
-        err = np.abs(a[fin] - b[fin])
-        tol = atol + rtol * np.abs(b[fin]) + ccoef * c[fin] + ncoef * nz[fin]
-        ratio = err / tol
-        i = int(np.argmax(ratio)) if ratio.size else 0
-        worst[k] = float(ratio[i]) if ratio.size else 0.0
-        assert worst[k] <= 1.0, (f"{k}: {int((ratio > 1).sum())} of {ratio.size} elements outside the bar; worst |err| {err[i]:.3e} vs "
-                                 f"tolerance {tol[i]:.3e} (want {b[fin][i]:.3e}, cond {c[fin][i]:.3e}, noise {nz[fin][i]:.3e})")
-    return worst
+        b, c = want[k].astype(np.float64), np.asarray(cond[k], np.float64)
+        assert got[k].shape == b.shape == c.shape, (k, got[k].shape, b.shape, c.shape)
+        out[k] = _bar_stats(got[k], b, atol + rtol * np.abs(b) + ccoef * c)
+        cover = np.mean(ccoef * c > atol + rtol * np.abs(b))  # share of elements whose bar is mostly the conditioning term
+        out[k]["frac_cond_term_dominates"] = float(cover)
+        e, t, w = out[k]["worst"]
+        assert out[k]["outside"] == 0, (f"blend sums {k}: {out[k]['outside']} of {out[k]['n']} elements outside the bar; worst |err| {e:.3e} "
+                                        f"vs tolerance {t:.3e} (want {w:.3e})")
+    return out
+
+
+def assert_chain_close(got, want, rtol=CHAIN_RTOL):
+    """Stage 2: per-Gaussian chain outputs against the oracle's chain on the SAME sums.  Returns {tensor: stats}."""
+    out = {}
+    for k in got:
+        if got[k].size == 0:
+            continue
+        b = want[k].astype(np.float64)
+        assert got[k].shape == b.shape, (k, got[k].shape, b.shape)
+        row = np.abs(np.where(np.isfinite(b), b, 0.0)).reshape(b.shape[0], -1).max(1).reshape((-1,) + (1,) * (b.ndim - 1))
+        out[k] = _bar_stats(got[k], b, rtol * (np.abs(np.where(np.isfinite(b), b, 0.0)) + row) + 1e-30)
+        e, t, w = out[k]["worst"]
+        assert out[k]["outside"] == 0, (f"chain output {k}: {out[k]['outside']} of {out[k]['n']} elements outside {rtol:g} relative; worst "
+                                        f"|err| {e:.3e} vs tolerance {t:.3e} (want {w:.3e})")
+    return out
+
+
+def two_stage_check(st, got, dL, chain_of=None, want_blend=None):
+    """The full check for one backward call.  `got`: the HIP outputs incl. "sums" (hip_backward_raw(..., capture=True)).
+    chain_of(sums dict) -> dict of expected chain outputs keyed like `got` (default: oracle.chain_backward on the activated operator);
+    want_blend: expected blend sums (default: the oracle's, in double).  Returns {tensor: stats} of both stages."""
+    from oracle import oracle
+
+    hs = unpack_sums(got["sums"])
+    # the blend-level outputs ARE those sums (dL_dopacity only where the operator returns it before the sigmoid chain)
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity"):
+        if k in got and chain_of is None:
+            assert np.array_equal(got[k], hs[k]), k
+    want = oracle.blend_backward(st, dL) if want_blend is None else want_blend
+    cond = oracle.blend_backward(st, dL, abs_terms=True)
+    stats = {"blend:" + k: v for k, v in assert_blend_sums_close({k: hs[k] for k in want}, want, cond).items()}
+    chain = oracle.chain_backward(st, hs) if chain_of is None else chain_of(hs)
+    keys = [k for k in got if k in chain and k != "sums" and (chain_of is not None or k in CHAIN_KEYS)]
+    stats.update({"chain:" + k: v for k, v in assert_chain_close({k: got[k] for k in keys}, chain).items()})
+    return stats
 
 
 def check_backward(ctx, st, dL, keys=None):
-    """HIP backward vs oracle backward for one forward state, at the element-wise bar."""
-    from oracle import oracle
-
-    got, want, cond = hip_backward_raw(ctx, dL), oracle.backward(st, dL), oracle.backward_condition(st, dL)
-    if keys is not None:
-        got = {k: got[k] for k in keys}
-    return assert_grads_close(got, want, cond)
-
-
-def raw_condition(raw_opacity, raw_scaling, raw_rotation, cond):
-    """Condition numbers of the raw-parameter gradients (gsr_backward_params) from those of the activated ones: the chain rule of
-    scene/gaussian_model.py:102-122 with every factor's magnitude -- sigmoid' = o (1 - o), exp' = s, and for
-    normalize: |(g - q (q.g)) / n| <= (c + |q| sum(|q| c)) / n."""
-    o = 1.0 / (1.0 + np.exp(-np.asarray(raw_opacity, np.float64).reshape(-1, 1)))
-    s = np.exp(np.asarray(raw_scaling, np.float64))
-    r = np.asarray(raw_rotation, np.float64)
-    n = np.maximum(np.sqrt((r * r).sum(1, keepdims=True)), 1e-12)
-    q = np.abs(r / n)
-    rot = lambda c: (np.asarray(c, np.float64) + q * (q * np.asarray(c, np.float64)).sum(1, keepdims=True)) / n
-    out = dict(dL_dmeans2D=cond["dL_dmeans2D"], dL_dxyz=cond["dL_dmeans3D"], dL_dfeatures_dc=cond["dL_dsh"][:, :1],
-               dL_dfeatures_rest=cond["dL_dsh"][:, 1:], dL_dopacity_raw=np.asarray(cond["dL_dopacity"], np.float64) * o * (1 - o),
-               dL_dscaling_raw=np.asarray(cond["dL_dscales"], np.float64) * s, dL_drotation_raw=rot(cond["dL_drotations"]))
-    if "noise:dL_dmeans3D" in cond:
-        out.update({"noise:dL_dxyz": cond["noise:dL_dmeans3D"], "noise:dL_dfeatures_dc": cond["noise:dL_dsh"][:, :1],
-                    "noise:dL_dfeatures_rest": cond["noise:dL_dsh"][:, 1:],
-                    "noise:dL_dscaling_raw": np.asarray(cond["noise:dL_dscales"], np.float64) * s,
-                    "noise:dL_drotation_raw": rot(cond["noise:dL_drotations"])})
-    return out
+    """HIP backward vs oracle backward for one forward state, at the two-stage element-wise bar.  Returns {stage:tensor: worst
+    |err| / tolerance}."""
+    got = hip_backward_raw(ctx, dL, capture=True)
+    stats = two_stage_check(st, got, dL)
+    return {k: v["worst_ratio"] for k, v in stats.items()}

@@ -107,6 +107,15 @@ def test_no_cpu_fallback():
         distCUDA2(torch.zeros(10, 3))
 
 
+def test_shipped_library_has_no_ablation_or_extra_flags():
+    """GSR_ABLATE / GSR_BIN_ABLATE (timing experiments that give wrong results on purpose) are 0 in the built .so and it was built
+    without make EXTRA=... (tools/build_ab.sh builds such variants elsewhere)."""
+    from based_on_point_cloud_partitions_amd import _lib
+
+    assert not os.environ.get("GSR_LIBRARY")
+    assert _lib.build_info() == f"abi={_lib.ABI_VERSION} ablate=0 bin_ablate=0 extra=[]"
+
+
 def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "based_on_point_cloud_partitions_amd")
     for dp, _, files in os.walk(pkg):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (assert_forward_bit_exact, assert_grads_close, check_backward, hip_backward_raw, hip_forward_raw, hip_settings,
+from helpers import (assert_forward_bit_exact, check_backward, two_stage_check, hip_backward_raw, hip_forward_raw, hip_settings,
                      oracle_forward, scene)
 from oracle import oracle
 
@@ -85,8 +85,14 @@ def test_snapshot_scene_against_committed_golden():
     assert np.array_equal(ctx["color"].cpu().numpy(), fx["out_color"])
     assert np.array_equal(ex["final_T"], fx["final_T"])
     dL = np.random.default_rng(9).standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
-    got = hip_backward_raw(ctx, dL)
-    assert_grads_close(got, {k: fx["g_" + k] for k in got}, oracle.backward_condition(oracle_forward(g, cam, bg=bg, sh_degree=3), dL))
+    # gradients: the oracle run here must reproduce the fixture's (drift guard; its double sums are added in OpenMP's dynamic order,
+    # hence a 1e-5 bar as in tests/test_oracle_golden.py), then the two-stage check of the HIP kernels against that oracle
+    st = oracle_forward(g, cam, bg=bg, sh_degree=3)
+    got = hip_backward_raw(ctx, dL, capture=True)
+    want = oracle.backward(st, dL)
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        np.testing.assert_allclose(want[k], fx["g_" + k], rtol=1e-5, atol=1e-7, err_msg=k)
+    two_stage_check(st, got, dL)
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GRAD_TOL, assert_forward_bit_exact, assert_grads_close, hip_settings, oracle_forward, raw_condition, scene
+from helpers import GRAD_TOL, assert_chain_close, unpack_sums, assert_forward_bit_exact, hip_settings, oracle_forward, scene, two_stage_check
 from oracle import oracle
 
 
@@ -94,17 +94,34 @@ def hip_params_forward(raw, cam, bg, deg, scale_modifier=1.0, device="cuda"):
     return dict(st=st, d=d, R=R, color=color, radii=radii, gb=gb, bb=bb, ib=ib, ex=ex, deg=deg, scale_modifier=scale_modifier)
 
 
-def hip_params_backward(ctx, dL):
+def hip_params_backward(ctx, dL, capture=True):
+    """gsr_backward_params; with capture also "sums": the blend sums the kernel's chain consumed (two-stage check)."""
+    from based_on_point_cloud_partitions_amd import _lib
     from based_on_point_cloud_partitions_amd import renderer as rn
 
     st, d = ctx["st"], ctx["d"]
-    out = rn.rasterize_gaussian_params_backward(
-        st.bg, d["xyz"], ctx["radii"], d["features_dc"], d["features_rest"], d["scaling"], d["rotation"], ctx["scale_modifier"],
-        st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, torch.as_tensor(dL).to(d["xyz"].device), ctx["deg"], st.campos,
-        ctx["gb"], ctx["R"], ctx["bb"], ctx["ib"], False)
-    torch.cuda.synchronize()
+    sums = torch.zeros(d["xyz"].shape[0], 12, device=d["xyz"].device) if capture else None
+    _lib.capture_sums(sums)
+    try:
+        out = rn.rasterize_gaussian_params_backward(
+            st.bg, d["xyz"], ctx["radii"], d["features_dc"], d["features_rest"], d["scaling"], d["rotation"], ctx["scale_modifier"],
+            st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, torch.as_tensor(dL).to(d["xyz"].device), ctx["deg"], st.campos,
+            ctx["gb"], ctx["R"], ctx["bb"], ctx["ib"], False)
+        torch.cuda.synchronize()
+    finally:
+        _lib.capture_sums(None)
     names = ["dL_dmeans2D", "dL_dxyz", "dL_dfeatures_dc", "dL_dfeatures_rest", "dL_dopacity_raw", "dL_dscaling_raw", "dL_drotation_raw"]
-    return {k: v.cpu().numpy() for k, v in zip(names, out)}
+    res = {k: v.cpu().numpy() for k, v in zip(names, out)}
+    if capture:
+        res["sums"] = sums.cpu().numpy()
+    return res
+
+
+def raw_chain(raw, st):
+    """sums -> expected raw-parameter gradients: the oracle's per-Gaussian chain on those sums, then the chain rule of the
+    activations (scene/gaussian_model.py:102-122)."""
+    return lambda hs: oracle.activate_backward(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(),
+                                               oracle.chain_backward(st, hs))
 
 
 def _params_parity(P, W, H, focal, seed=0, deg=3, m=None, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, **kw):
@@ -118,11 +135,10 @@ def _params_parity(P, W, H, focal, seed=0, deg=3, m=None, bg=(0.0, 0.0, 0.0), sc
     assert np.array_equal(ex["clamped"][vis], st["clamped"][vis])
     assert np.array_equal(ex["cov3D"].view(np.uint32)[vis], st["cov3D"].view(np.uint32)[vis])
     dL = np.random.default_rng(seed + 100).standard_normal((3, H, W)).astype(np.float32)
-    want = oracle.activate_backward(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(), oracle.backward(st, dL))
-    cond = raw_condition(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(), oracle.backward_condition(st, dL))
     got = hip_params_backward(ctx, dL)
-    assert got["dL_dfeatures_rest"].shape == want["dL_dfeatures_rest"].shape
-    assert_grads_close(got, want, cond)
+    assert got["dL_dfeatures_rest"].shape == (raw["features_rest"].shape[0], raw["features_rest"].shape[1], 3)
+    two_stage_check(st, got, dL, chain_of=raw_chain(raw, st))  # blend sums vs the oracle's, raw gradients vs the chain on the HIP sums
+    got.pop("sums")
     return st, ctx, got
 
 
@@ -155,23 +171,21 @@ def test_params_operator_zero_norm_quaternion_and_empty_model():
     ctx = hip_params_forward(raw, cam, (0.0, 0.0, 0.0), 3)
     assert_forward_bit_exact(ctx, st)
     dL = np.ones((3, 64, 64), np.float32)
-    want = oracle.activate_backward(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(), oracle.backward(st, dL))
-    cond = raw_condition(raw["opacity"].numpy(), raw["scaling"].numpy(), raw["rotation"].numpy(), oracle.backward_condition(st, dL))
     got = hip_params_backward(ctx, dL)
+    want = raw_chain(raw, st)(unpack_sums(got["sums"]))
     fin = np.isfinite(want["dL_drotation_raw"]).all(axis=1)
     assert np.array_equal(np.isfinite(got["dL_drotation_raw"]).all(axis=1), fin)
-    for k in got:
-        if k != "dL_drotation_raw":
-            assert_grads_close({k: got[k]}, {k: want[k]}, cond)
+    rot_got, rot_want = got.pop("dL_drotation_raw"), want["dL_drotation_raw"]
+    two_stage_check(st, got, dL, chain_of=lambda hs: {k: v for k, v in raw_chain(raw, st)(hs).items() if k != "dL_drotation_raw"})
     # gradients of the clamped quaternions are g / 1e-12: compare in relative terms
-    a, b = got["dL_drotation_raw"][:50].astype(np.float64), want["dL_drotation_raw"][:50].astype(np.float64)
+    a, b = rot_got[:50].astype(np.float64), rot_want[:50].astype(np.float64)
     ok = np.isfinite(b)
     assert np.all(np.abs(a[ok] - b[ok]) <= 1e-4 * max(1.0, np.abs(b[ok]).max()))
-    assert_grads_close({"r": got["dL_drotation_raw"][50:]}, {"r": want["dL_drotation_raw"][50:]}, {"r": cond["dL_drotation_raw"][50:]})
+    assert_chain_close({"r": rot_got[50:]}, {"r": rot_want[50:]})
     raw0 = {k: v[:0] for k, v in raw.items()}
     ctx0 = hip_params_forward(raw0, cam, (0.1, 0.2, 0.3), 3)
     assert ctx0["R"] == 0 and torch.all(ctx0["color"] == 0)
-    got0 = hip_params_backward(ctx0, dL)
+    got0 = hip_params_backward(ctx0, dL, capture=False)
     assert got0["dL_dfeatures_rest"].shape == (0, 15, 3) and got0["dL_dopacity_raw"].shape == (0, 1)
 
 
