@@ -312,10 +312,10 @@ static void launch_render_head(int P, int W, int H, void* geom_buffer, void* bin
         if (!gsr_launch_emit_partition(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
                                        (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets),
                                        (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets),
-                                       (uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), s))
+                                       (uint32_t*)(g + G.wg_first), (uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), s))
             gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched), (const uint32_t*)(g + G.block_offsets),
                             (uint32_t*)(g + G.point_offsets), (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets),
-                            nullptr, nullptr, s);
+                            (uint32_t*)(g + G.wg_first), nullptr, nullptr, s);
     }
     StageTimer t(GSR_STAGE_SORT, s);
     gsr_launch_tile_binning_head(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
@@ -369,7 +369,7 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
             StageTimer t(GSR_STAGE_EMIT, s);
             gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
                             (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets),
-                            (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets), ka, va, s);
+                            (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets), (uint32_t*)(g + G.wg_first), ka, va, s);
         }
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));  // rasterizer_impl.cu:300-308
         int in_b;
@@ -501,6 +501,10 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     a.tiles_touched = (const uint32_t*)(g + G.tiles_touched);
     a.point_offsets = (const uint32_t*)(g + G.point_offsets);
     a.row_offsets = (const uint32_t*)(g + G.row_offsets);
+    // the work split stored by the forward's offset kernels; with no instance at all they did not run (and the split is the plain one)
+    a.wg_first = (R > 0 && gsr_variant("GB_BALANCED", 1)) ? (const uint32_t*)(g + G.wg_first) : nullptr;
+    a.row_total = (const uint32_t*)(g + G.row_block_offsets) + (P + 255) / 256;
+    a.rows_bound = (uint32_t)R;
     a.grad_rows = (const float*)scratch;
     a.sums_out = g_capture_sums;
     { StageTimer t(GSR_STAGE_GAUSS_BWD, s); gsr_launch_gaussian_backward(a, s); }

@@ -275,6 +275,7 @@ __global__ void __launch_bounds__(SLICE_THREADS) emit_partition_kernel(int P, Ba
                                                                         uint32_t* __restrict__ point_offsets,
                                                                         const uint32_t* __restrict__ row_block_offsets,
                                                                         uint32_t* __restrict__ row_offsets,
+                                                                        uint32_t* __restrict__ wg_first,
                                                                         uint32_t* __restrict__ band_count, uint32_t* __restrict__ band_list)
 {
     __shared__ uint32_t cnt[NB_MAX], base[NB_MAX];
@@ -318,6 +319,7 @@ __global__ void __launch_bounds__(SLICE_THREADS) emit_partition_kernel(int P, Ba
             const uint32_t end = bs + incl[e], end_r = bs_r + incl_r[e];
             point_offsets[idx] = end;
             row_offsets[idx] = end_r;
+            gsr_part_store(wg_first, P, idx, end_r - nr[e], end_r, row_block_offsets[(P + 255) >> 8]);
             if (n[e] != 0) {
                 float* rec = splat + (size_t)idx * GSR_SPLAT_F;
                 rec[SP_ROWBASE] = __uint_as_float(end_r - nr[e]);
@@ -939,8 +941,8 @@ size_t gsr_band_list_bytes(int P, int W, int H)
 }
 
 bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                               uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* band_count,
-                               uint32_t* band_mem, hipStream_t s)
+                               uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* wg_first,
+                               uint32_t* band_count, uint32_t* band_mem, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     int nb_, bh_;
@@ -948,7 +950,7 @@ bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t
     const BandGeom G = band_geom(gx, gy);
     // the band counters were zeroed by scan_blocks_kernel (preprocess.hip)
     hipLaunchKernelGGL(emit_partition_kernel, dim3((P + SLICE_THREADS * PART_ITEMS - 1) / (SLICE_THREADS * PART_ITEMS)), dim3(SLICE_THREADS), 0, s, P,
-                       G, splat, tiles_touched, block_offsets, point_offsets, row_block_offsets, row_offsets, band_count,
+                       G, splat, tiles_touched, block_offsets, point_offsets, row_block_offsets, row_offsets, wg_first, band_count,
                        band_mem + GSR_BAND_COUNTERS);
     return true;
 }

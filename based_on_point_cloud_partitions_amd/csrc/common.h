@@ -31,7 +31,8 @@ enum GradRowField { GR_MX = 0, GR_MY = 1, GR_CX = 2, GR_CY = 3, GR_CW = 4, GR_OP
 struct GeomLayout {
     size_t splat, cov3D, clamped, tiles_touched, point_offsets, block_sums, block_offsets, total, radii,
         row_offsets /* inclusive prefix of the Gaussians' gradient-row counts */, row_block_sums, row_block_offsets,
-        band_count /* ids per band of the banded tile binning: zeroed by the scan kernel, filled by emit_partition_kernel */, bytes;
+        band_count /* ids per band of the banded tile binning: zeroed by the scan kernel, filled by emit_partition_kernel */,
+        wg_first /* work split of the per-Gaussian backward: first Gaussian of every workgroup (gsr_part_*) */, bytes;
 };
 struct ImageLayout {
     size_t final_T, n_contrib, ranges, bytes;
@@ -59,6 +60,23 @@ typedef float gsr_f3u __attribute__((ext_vector_type(3), aligned(4)));
 
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- work split of the per-Gaussian backward (gaussian_backward.hip) ---------------------------------------------------------
+// A workgroup's cost is its Gaussians (the chain: ~600 B and ~300 instructions each) plus their gradient rows (48 B each): Gaussian
+// i starts at cost f(i) = 8 i + (gradient rows before i) and belongs to workgroup f(i) >> sh.  sh = 10 (1024 cost units = 128
+// Gaussians without rows, or 1024 rows) unless that needs more than gsr_part_cap(P) workgroups -- a scene with more than ~8 rows per
+// Gaussian -- in which case sh grows and a workgroup walks its Gaussians in passes.  The kernels that compute the row offsets
+// (emit_partition_kernel / emit_keys_kernel) store every workgroup's first Gaussian in GeomLayout::wg_first, so the split costs the
+// backward one load per workgroup and its duration no longer depends on the order of the Gaussians in memory (a spatially sorted
+// model puts all the many-row Gaussians of a close-up region into the same workgroups).
+__host__ __device__ static inline uint32_t gsr_part_cap(int P) { return 2u * (((uint32_t)(P > 0 ? P : 1) + 127u) / 128u) + 8u; }
+__host__ __device__ static inline int gsr_part_shift(int P, uint32_t total_rows)
+{
+    const unsigned long long f = 8ull * (unsigned long long)(P > 0 ? P : 0) + total_rows;
+    int sh = 10;
+    while ((f >> sh) + 1ull > (unsigned long long)gsr_part_cap(P)) sh++;
+    return sh;
+}
+
 static inline GeomLayout gsr_geom_layout(int P)
 {
     GeomLayout L;
@@ -77,6 +95,7 @@ static inline GeomLayout gsr_geom_layout(int P)
     L.row_block_sums = o; o = gsr_align(o + nb * 4);
     L.row_block_offsets = o; o = gsr_align(o + nb * 4 + 16);  // + the total
     L.band_count = o; o = gsr_align(o + GSR_BAND_COUNTERS * 4);
+    L.wg_first = o; o = gsr_align(o + ((size_t)gsr_part_cap(P) + 1) * 4);
     L.bytes = o;
     return L;
 }
@@ -165,14 +184,15 @@ void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* b
 // zero64 (may be NULL): 64 words the kernel zeroes (the band counters of the tile binning, filled by the next stage)
 void gsr_launch_scan_blocks2(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total, const uint32_t* in2,
                              uint32_t* out2, unsigned long long* mailbox, uint32_t seq, uint32_t* zero64, hipStream_t s);
+// row_block_offsets[ceil(P / 256)] is the total number of gradient rows (scan_blocks2); wg_first: GeomLayout::wg_first
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                     uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint64_t* keys, uint32_t* vals,
-                     hipStream_t s);
+                     uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* wg_first,
+                     uint64_t* keys, uint32_t* vals, hipStream_t s);
 // banded tile binning: the instance / gradient-row offsets of gsr_launch_emit (no keys) and the per-band id lists in one pass
 // over the splat records; false (nothing launched) when the banded binning does not apply to this tile grid
 bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                               uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* band_count,
-                               uint32_t* band_mem, hipStream_t s);
+                               uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* wg_first,
+                               uint32_t* band_count, uint32_t* band_mem, hipStream_t s);
 // true (and the band count / height in tile rows) when the banded tile binning applies to this tile grid
 bool gsr_band_geometry(int gx, int gy, int* nb, int* bh);
 // returns 0 if the sorted pairs end in (ka,va), 1 if in (kb,vb)
@@ -210,6 +230,9 @@ struct GaussBackwardArgs {
     int raw;
     const float *features_dc, *features_rest;
     float *dL_dfeatures_dc, *dL_dfeatures_rest;
+    const uint32_t* wg_first;   // GeomLayout::wg_first (NULL: every workgroup takes GB_BLOCK consecutive Gaussians)
+    const uint32_t* row_total;  // total number of gradient rows (row_block_offsets[ceil(P / 256)])
+    uint32_t rows_bound;        // what the host knows about it: <= num_rendered
     float* sums_out;  // test hook (gsr_debug_capture_sums): the nine reduced blend sums per Gaussian, [P][GSR_GROW_F], or NULL
 };
 void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s);
@@ -421,6 +444,18 @@ __device__ __forceinline__ bool gsr_tile_cannot_touch(float mx, float my, float 
 __device__ __forceinline__ uint32_t gsr_splat_rows(uint32_t mask_lo, uint32_t mask_hi, uint32_t big, uint32_t tiles_touched)
 {
     return big ? tiles_touched : (uint32_t)(__popc(mask_lo) + __popc(mask_hi));
+}
+
+// Called by the thread that has just computed Gaussian idx's inclusive gradient-row prefix: records idx + 1 as the first Gaussian of
+// every workgroup of the per-Gaussian backward that starts between Gaussian idx and idx + 1 (gsr_part_shift above).
+__device__ __forceinline__ void gsr_part_store(uint32_t* __restrict__ wg_first, int P, int idx, uint32_t rows_excl, uint32_t rows_incl,
+                                               uint32_t total_rows)
+{
+    const int sh = gsr_part_shift(P, total_rows);
+    const uint32_t w0 = (uint32_t)((8ull * (unsigned long long)idx + rows_excl) >> sh);
+    const uint32_t w1 = (uint32_t)((8ull * (unsigned long long)(idx + 1) + rows_incl) >> sh);
+    for (uint32_t w = w0 + 1; w <= w1; w++) wg_first[w] = (uint32_t)(idx + 1);
+    if (idx == 0) wg_first[0] = 0u;
 }
 
 // relative margin of the reach tests as a function of the conic's conditioning kappa = cx cz / det (see gsr_reach_mask):

@@ -35,9 +35,99 @@ struct GaussBackwardPtrs {
     const float* __restrict__ features_dc; const float* __restrict__ features_rest;
     float* __restrict__ dL_dfeatures_dc; float* __restrict__ dL_dfeatures_rest;
     float* __restrict__ sums_out;
+    const uint32_t* __restrict__ wg_first; const uint32_t* __restrict__ row_total;
     int P, D, M, has_shs, has_scales, lds_floats;
     float scale_modifier, tan_fovx, tan_fovy;
 };
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_read(float v)  // the DPP-selected lane's v; 0 where the selection has no source or the row is masked
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+
+// Balanced summation of the gradient rows of one pass (`cnt` <= BS consecutive Gaussians whose rows are the contiguous range
+// [s_off[0], s_off[cnt]) of grad_rows; s_off[k] = first row of Gaussian k, both in LDS).  One LANE per ROW: the waves take equal
+// shares of the rows (cut at Gaussian boundaries), walk them 64 at a time -- coalesced 16-byte loads, the next step's rows requested
+// before this step is reduced -- and run a SEGMENTED inclusive scan over the 64 lanes (segments = Gaussians): four row_shr levels
+// inside the rows of 16 lanes, row_bcast:15 and row_bcast:31 across them, a scalar carry from step to step.  The lane of a Gaussian's
+// last row then holds its nine sums and stores them to s_sum[k][9].  Every Gaussian's rows are added in a tree whose shape depends
+// only on the row numbering (bitwise reproducible), and the time of a pass is its number of rows / 64, however they are distributed
+// over the Gaussians: the earlier scheme (every thread adds its own Gaussian's rows) took as long as the Gaussian with most rows,
+// per chunk -- 2.2x slower on a spatially sorted model, whose workgroups hold either many-row or few-row Gaussians.
+template <int BS>
+__device__ __forceinline__ void reduce_rows_balanced(const float4* __restrict__ g4, const uint32_t* s_off, float* s_sum, int cnt)
+{
+    constexpr int NW = BS / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t rb = s_off[0], re = s_off[cnt];
+    if (rb == re) return;
+    auto first_at = [&](uint32_t row) -> int {  // first k in [0, cnt] with s_off[k] >= row (wave-uniform)
+        int lo = 0, hi = cnt;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] >= row) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const uint32_t share = (re - rb + NW - 1) / NW;
+    const int ka = wave == 0 ? 0 : first_at(rb + wave * share);
+    const int kb = wave == NW - 1 ? cnt : first_at(rb + (wave + 1) * share);
+    const uint32_t ws = s_off[ka], we = s_off[kb];
+    if (ws >= we) return;
+    float carry[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) carry[i] = 0.f;
+    bool cont = false;  // the segment of the previous step's last row goes on in this step
+    float4 n0, n1, n2;
+    auto request = [&](uint32_t base) {
+        const uint32_t r = base + lane;
+        n0 = n1 = n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < we) {
+            n0 = g4[(size_t)r * 3];
+            n1 = g4[(size_t)r * 3 + 1];
+            n2 = g4[(size_t)r * 3 + 2];
+        }
+    };
+    request(ws);
+    const uint32_t l15 = lane & 15, l31 = lane & 31;
+    for (uint32_t base = ws; base < we; base += 64) {
+        float v[9] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x};
+        if (base + 64 < we) request(base + 64);
+        const uint32_t r = base + lane;
+        const bool valid = r < we;
+        // owner: the last Gaussian k in [ka, kb) with s_off[k] <= r (Gaussians without rows share their successor's offset)
+        int lo = ka, hi = kb;  // invariant: s_off[lo] <= r < s_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= r) lo = mid; else hi = mid;
+        }
+        const uint32_t dist = valid ? r - s_off[lo] : 0u;  // rows back to the first row of this lane's Gaussian
+        const bool ends = valid && r + 1 == s_off[lo + 1];
+        if (lane == 0 && cont) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) v[i] += carry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            float t;
+            t = dpp_read<0x111, 0xf>(v[i]); v[i] = dist >= 1u ? v[i] + t : v[i];    // row_shr:1
+            t = dpp_read<0x112, 0xf>(v[i]); v[i] = dist >= 2u ? v[i] + t : v[i];    // row_shr:2
+            t = dpp_read<0x114, 0xf>(v[i]); v[i] = dist >= 4u ? v[i] + t : v[i];    // row_shr:4
+            t = dpp_read<0x118, 0xf>(v[i]); v[i] = dist >= 8u ? v[i] + t : v[i];    // row_shr:8
+            t = dpp_read<0x142, 0xa>(v[i]); v[i] = dist > l15 ? v[i] + t : v[i];    // row_bcast:15 -> rows 1, 3
+            t = dpp_read<0x143, 0xc>(v[i]); v[i] = dist > l31 ? v[i] + t : v[i];    // row_bcast:31 -> rows 2, 3
+        }
+        if (ends) {
+            float* o = s_sum + lo * 9;
+#pragma unroll
+            for (int i = 0; i < 9; i++) o[i] = v[i];
+        }
+        cont = __builtin_amdgcn_readlane((int)(valid && !ends), 63) != 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) carry[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
+    }
+}
 
 // RAW (gsr_backward_params): scales / rotations are the pre-activation parameters; the chain rule through exp / sigmoid /
 // normalize is applied here and dL/dSH leaves LDS as the two tensors dL/dfeatures_dc, dL/dfeatures_rest -- the autograd
@@ -46,15 +136,34 @@ struct GaussBackwardPtrs {
 // 16-byte loads at the start of its chain and stores its dL/dSH row the same way -- no SH tile in LDS, so the workgroup's LDS is
 // the small gradient-row buffer alone and twice as many waves are in flight (the kernel is latency-bound: with half the waves
 // it takes 1.5x as long).  Culled Gaussians read no SH at all.
-template <bool RAW, int BS, bool DIRECT, int RK = 1>
+// BAL: the cost-balanced work split and the lane-per-row summation (the default); !BAL: BS consecutive Gaussians per workgroup, every
+// thread adds its own Gaussian's rows (GSR_GB_BALANCED=0, and scenes without any instance).
+template <bool RAW, int BS, bool DIRECT, int RK, bool BAL>
 __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
 {
     extern __shared__ float s_tile[];  // [BS][3M + 1]
-    const int idx = blockIdx.x * BS + threadIdx.x;
+    // this workgroup's Gaussians: the cost-balanced split stored by the forward (gsr_part_*, common.h), or BS consecutive ones
+    int w_first, w_last;
+    if (BAL) {
+        const uint32_t total = a.row_total[0];
+        const uint32_t nw = (uint32_t)((8ull * (unsigned long long)a.P + total) >> gsr_part_shift(a.P, total)) + 1u;
+        if (blockIdx.x >= nw) return;
+        w_first = (int)a.wg_first[blockIdx.x];
+        w_last = blockIdx.x + 1 < nw ? (int)a.wg_first[blockIdx.x + 1] : a.P;
+    } else {
+        w_first = blockIdx.x * BS;
+        w_last = min(a.P, w_first + BS);
+    }
     const int M = a.M, n3 = 3 * M, stride = n3 + 1;
-    const int rows = min(BS, a.P - (int)blockIdx.x * BS);
-    const size_t tile_base = (size_t)blockIdx.x * BS * n3;
-    const bool valid = idx < a.P;
+    // blockIdx.y: a workgroup of the split holds more than BS Gaussians only when the scene has more than ~8 gradient rows per Gaussian
+    // (gsr_part_shift > 10); its Gaussians are then shared among the workgroups of its grid column, BS each
+    const int gbase = w_first + (int)blockIdx.y * BS;
+    if (gbase >= w_last) return;
+    {
+    const int idx = gbase + threadIdx.x;
+    const int rows = min(BS, w_last - gbase);
+    const size_t tile_base = (size_t)gbase * n3;
+    const bool valid = (int)threadIdx.x < rows;
     const bool visible = valid && a.radii[idx] > 0;
 
     // the Gaussian's own parameters: requested here so that they arrive while the gradient rows are summed (the chain below would
@@ -78,8 +187,25 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     // ascending row order (fixed order -> bitwise reproducible).  Reading them per thread straight from HBM serialises
     // one dependent round trip per row and was 60 % of this kernel.
     float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {
-        const int first = blockIdx.x * BS, last = min(a.P, first + BS);
+    if (BAL) {
+        // s_off[k] = first gradient row of Gaussian gbase + k (exclusive prefix of the row counts), s_off[rows] = the end
+        uint32_t* s_off = reinterpret_cast<uint32_t*>(s_tile);
+        float* s_sum = s_tile + BS + 1;
+        if ((int)threadIdx.x <= rows) {
+            const int i = gbase + (int)threadIdx.x;
+            s_off[threadIdx.x] = i == 0 ? 0u : a.row_offsets[i - 1];
+        }
+        if (BS + threadIdx.x <= (unsigned)rows) s_off[BS] = a.row_offsets[gbase + BS - 1];  // (thread 0 when the pass is full)
+        __syncthreads();
+        reduce_rows_balanced<BS>(reinterpret_cast<const float4*>(a.grad_rows), s_off, s_sum, rows);
+        __syncthreads();
+        if (valid && s_off[threadIdx.x + 1] != s_off[threadIdx.x]) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) g[i] = s_sum[threadIdx.x * 9 + i];
+        }
+        __syncthreads();  // s_tile is reused below
+    } else {
+        const int first = gbase, last = gbase + rows;
         uint32_t begin, end, my_off = 0, my_n = 0;
         // one row per reachable instance, numbered by the preprocess kernel's tile masks (render_backward.hip)
         begin = first == 0 ? 0u : a.row_offsets[first - 1];
@@ -129,8 +255,8 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     }
 
     if (RAW && !DIRECT) {
-        sh_cols_load(a.features_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
-        if (n3 > 3) sh_cols_load(a.features_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
+        sh_cols_load(a.features_dc + (size_t)gbase * 3, s_tile, rows, 3, stride, 0);
+        if (n3 > 3) sh_cols_load(a.features_rest + (size_t)gbase * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
     } else if (!DIRECT && a.has_shs) sh_tile_load(a.shs + tile_base, s_tile, rows, n3, stride);
     if (!DIRECT) __syncthreads();
     float shr[DIRECT ? 48 : 1];
@@ -441,8 +567,8 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
             for (int k = 0; k < 16; k++) s_tile[threadIdx.x * 17 + k] = w[(16 * c + k) / 3] * dRGBo[(16 * c + k) % 3];
             __syncthreads();
             if (RAW) {  // the row splits into dL/dfeatures_dc (floats 0..2) and dL/dfeatures_rest (3..47): coalesced dword stores
-                float* o_dc = a.dL_dfeatures_dc + (size_t)blockIdx.x * BS * 3;
-                float* o_rest = a.dL_dfeatures_rest + (size_t)blockIdx.x * BS * 45;
+                float* o_dc = a.dL_dfeatures_dc + (size_t)gbase * 3;
+                float* o_rest = a.dL_dfeatures_rest + (size_t)gbase * 45;
                 for (int f = threadIdx.x; f < rows * 16; f += BS) {
                     const int r = f >> 4, j = 16 * c + (f & 15);
                     const float v = s_tile[r * 17 + (f & 15)];
@@ -462,9 +588,10 @@ __global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs
     }
     __syncthreads();
     if (RAW) {
-        sh_cols_store(a.dL_dfeatures_dc + (size_t)blockIdx.x * BS * 3, s_tile, rows, 3, stride, 0);
-        if (n3 > 3) sh_cols_store(a.dL_dfeatures_rest + (size_t)blockIdx.x * BS * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
+        sh_cols_store(a.dL_dfeatures_dc + (size_t)gbase * 3, s_tile, rows, 3, stride, 0);
+        if (n3 > 3) sh_cols_store(a.dL_dfeatures_rest + (size_t)gbase * (n3 - 3), s_tile, rows, n3 - 3, stride, 3);
     } else if (n3 > 0) sh_tile_store(a.dL_dsh + tile_base, s_tile, rows, n3, stride);
+    }
 }
 
 }  // namespace
@@ -483,6 +610,7 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     p.features_dc = a.features_dc; p.features_rest = a.features_rest;
     p.dL_dfeatures_dc = a.dL_dfeatures_dc; p.dL_dfeatures_rest = a.dL_dfeatures_rest;
     p.sums_out = a.sums_out;
+    p.wg_first = a.wg_first; p.row_total = a.row_total;
     p.P = a.P; p.D = a.D; p.M = a.M; p.has_shs = a.has_shs; p.has_scales = a.has_scales;
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     const int bs = gsr_variant("GB_BLOCK", 128);
@@ -495,18 +623,27 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     if (!direct && lds < (size_t)4 * bs * GSR_GROW_F * 4) lds = (size_t)4 * bs * GSR_GROW_F * 4;
     p.lds_floats = (int)(lds / 4);
     lds += (size_t)gsr_variant("LDS_PAD", 0);
-    const dim3 grid((a.P + bs - 1) / bs), block(bs);
+    // balanced split: gsr_part_cap(P) workgroups cover every scene (the ones beyond the split's end leave at once); a second grid
+    // dimension only when the split's workgroups may hold more than `bs` Gaussians (rows <= instances: an upper bound of the shift)
+    const uint32_t cols = a.wg_first ? (uint32_t)(((128u << (gsr_part_shift(a.P, a.rows_bound) - 10)) + bs - 1) / bs) : 1u;
+    const dim3 grid(a.wg_first ? gsr_part_cap(a.P) : (uint32_t)((a.P + bs - 1) / bs), cols), block(bs);
+#define GB_LAUNCH(RAW_, BS_, DIRECT_, RK_)                                                                                      \
+    do {                                                                                                                        \
+        if (a.wg_first) hipLaunchKernelGGL((gaussian_backward_kernel<RAW_, BS_, DIRECT_, RK_, true>), grid, block, lds, s, p, h_x, h_y);  \
+        else hipLaunchKernelGGL((gaussian_backward_kernel<RAW_, BS_, DIRECT_, RK_, false>), grid, block, lds, s, p, h_x, h_y);  \
+    } while (0)
     if (bs == 256) {
-        if (a.raw && direct) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256, true>), grid, block, lds, s, p, h_x, h_y);
-        else if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 256, false>), grid, block, lds, s, p, h_x, h_y);
-        else if (direct && rk == 2) hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, true, 2>), grid, block, lds, s, p, h_x, h_y);
-        else if (direct) hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, true>), grid, block, lds, s, p, h_x, h_y);
-        else hipLaunchKernelGGL((gaussian_backward_kernel<false, 256, false>), grid, block, lds, s, p, h_x, h_y);
+        if (a.raw && direct) GB_LAUNCH(true, 256, true, 1);
+        else if (a.raw) GB_LAUNCH(true, 256, false, 1);
+        else if (direct && rk == 2) GB_LAUNCH(false, 256, true, 2);
+        else if (direct) GB_LAUNCH(false, 256, true, 1);
+        else GB_LAUNCH(false, 256, false, 1);
     } else {
-        if (a.raw && direct) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128, true>), grid, block, lds, s, p, h_x, h_y);
-        else if (a.raw) hipLaunchKernelGGL((gaussian_backward_kernel<true, 128, false>), grid, block, lds, s, p, h_x, h_y);
-        else if (direct && rk == 2) hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, true, 2>), grid, block, lds, s, p, h_x, h_y);
-        else if (direct) hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, true>), grid, block, lds, s, p, h_x, h_y);
-        else hipLaunchKernelGGL((gaussian_backward_kernel<false, 128, false>), grid, block, lds, s, p, h_x, h_y);
+        if (a.raw && direct) GB_LAUNCH(true, 128, true, 1);
+        else if (a.raw) GB_LAUNCH(true, 128, false, 1);
+        else if (direct && rk == 2) GB_LAUNCH(false, 128, true, 2);
+        else if (direct) GB_LAUNCH(false, 128, true, 1);
+        else GB_LAUNCH(false, 128, false, 1);
     }
+#undef GB_LAUNCH
 }

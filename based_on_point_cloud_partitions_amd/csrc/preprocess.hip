@@ -303,7 +303,8 @@ __global__ void __launch_bounds__(256) emit_keys_kernel(int P, int gx, int gy, f
                                                         const uint32_t* __restrict__ block_offsets,
                                                         uint32_t* __restrict__ point_offsets,
                                                         const uint32_t* __restrict__ row_block_offsets, uint32_t* __restrict__ row_offsets,
-                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                        uint32_t* __restrict__ wg_first, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -330,6 +331,7 @@ __global__ void __launch_bounds__(256) emit_keys_kernel(int P, int gx, int gy, f
     uint32_t off = end - n;
     point_offsets[idx] = end;
     row_offsets[idx] = base_r + incl_r;
+    gsr_part_store(wg_first, P, idx, base_r + incl_r - nr, base_r + incl_r, row_block_offsets[(P + 255) >> 8]);
     if (n == 0) return;
     float* rec = splat + (size_t)idx * GSR_SPLAT_F;
     rec[SP_ROWBASE] = __uint_as_float(base_r + incl_r - nr);
@@ -409,12 +411,12 @@ void gsr_launch_scan_blocks2(int nblocks, const uint32_t* block_sums, uint32_t* 
 }
 
 void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                     uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint64_t* keys, uint32_t* vals,
-                     hipStream_t s)
+                     uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* wg_first,
+                     uint64_t* keys, uint32_t* vals, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, splat, tiles_touched, block_offsets,
-                       point_offsets, row_block_offsets, row_offsets, keys, vals);
+                       point_offsets, row_block_offsets, row_offsets, wg_first, keys, vals);
 }
 
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s)

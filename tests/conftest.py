@@ -31,6 +31,20 @@ def pytest_configure(config):
     RCCL_CHILD["out"] = out
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """GPU sessions leave the worst |err| / tolerance of every gradient tensor (two-stage bar, tests/helpers.py) under gpurun_out/."""
+    try:
+        import json
+
+        import helpers
+        if helpers.WORST:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            json.dump(dict(worst_ratio=helpers.WORST, GRAD_COND=helpers.GRAD_COND, CHAIN_RTOL=helpers.CHAIN_RTOL, exitstatus=int(exitstatus)),
+                      open(os.path.join(ROOT, "gpurun_out", "grad_worst.json"), "w"), indent=1, sort_keys=True)
+    except Exception:  # noqa: BLE001 -- reporting only
+        pass
+
+
 def pytest_unconfigure(config):
     p = RCCL_CHILD["proc"]
     if p is not None and p.poll() is None:
