@@ -105,6 +105,7 @@ constexpr uint32_t GSR_NO_ROW = 0x0FFFFFFFu;  // 28 bits of gradient-row index (
 // Timing ablations (results are WRONG on purpose; never defined in the shipped build): make EXTRA=-DGSR_ABLATE=n
 //   1: plain sum instead of the wave reduction   2: 1 + nothing written to LDS   3: no blend math after the alpha decision
 //   4: nothing after the range test              5: no walk at all (staging + flush only)
+//   6: (alone) no zero rows for the entries behind the tile's last contributor
 #ifndef GSR_BWD_WPE
 #define GSR_BWD_WPE 0  // experiment: waves per SIMD the register allocation aims at (0: 8)
 #endif
@@ -120,6 +121,7 @@ constexpr uint32_t GSR_NO_ROW = 0x0FFFFFFFu;  // 28 bits of gradient-row index (
 #ifndef GSR_ABLATE
 #define GSR_ABLATE 0
 #endif
+#define GSR_ABL (GSR_ABLATE == 6 ? 0 : GSR_ABLATE)  // the walk's ablation level
 
 // FAST_EXP: G = exp(power) from the hardware exp2 (v_exp_f32, <= 1e-6 relative off gsr_expf_blend on the range that can pass), 2 issue slots
 // instead of the 9 instructions of the forward's fully specified gsr_expf_blend.  The alpha >= 1/255 decision must be the forward's: when
@@ -265,7 +267,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                 bq[q] = __builtin_amdgcn_ballot_w64(((s_row[64 * w + lane] >> (28 + q_first + q)) & 1u) != 0u);
                 U |= bq[q];
             }
-            if (GSR_ABLATE >= 5) U = 0ull;
+            if (GSR_ABL >= 5) U = 0ull;
             if (U == 0ull) continue;
             // PIPE: the operands of the NEXT entry are requested from LDS after this entry's quadrants have been visited and before its
             // wave reduction: the registers are free by then and the round trip hides behind the reduction
@@ -301,7 +303,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     // compare's result mask): combining them and testing "any lane" is scalar work
                     const unsigned long long m_maybe = act[q] & __builtin_amdgcn_ballot_w64(power >= b.z);  // power > 0: below
                     if (m_maybe == 0ull) return false;
-                    if (GSR_ABLATE >= 4) { T[q] += power; return false; }
+                    if (GSR_ABL >= 4) { T[q] += power; return false; }
                     unsigned long long m_c = m_maybe & __builtin_amdgcn_ballot_w64(power <= 0.0f);
                     float G = FAST_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gsr_expf_blend(power);
                     float alpha = fminf(0.99f, b.y * G);
@@ -312,7 +314,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                     }
                     m_c &= __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
                     if (m_c == 0ull) return false;
-                    if (GSR_ABLATE >= 3) { T[q] += alpha; return false; }
+                    if (GSR_ABL >= 3) { T[q] += alpha; return false; }
                     // From here all 64 lanes run the same straight-line code.  A lane that does not contribute is given alpha = G = 0:
                     // then T/(1-0) = T, its gradient terms vanish, and the colour recurrence (backward.cu:515) leaves accum unchanged
                     float Ge, ae;
@@ -368,9 +370,9 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                         c0 = AT1 * dL0[1]; c1 = AT1 * dL1[1]; c2 = AT1 * dL2[1];
                     }
                     const float swy = sw * dy;
-#if GSR_ABLATE >= 1
+#if GSR_ABL >= 1
                     const float tot = ((sw + swx) + (swy + sxx)) + ((swx * dy + swy * dy) + (c0 + c1)) + c2;
-                    if (GSR_ABLATE < 2 ? writer : tot == 12345.678f) atomicAdd(&my_acc[j * NV + my_slot], tot);
+                    if (GSR_ABL < 2 ? writer : tot == 12345.678f) atomicAdd(&my_acc[j * NV + my_slot], tot);
 #else
                     const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M2);
                     if (writer) atomicAdd(&my_acc[j * NV + my_slot], tot);  // LDS
@@ -403,7 +405,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             }
         }
     }
-#if GSR_ABLATE >= 3
+#if GSR_ABL >= 3
     {   // keeps the ablated walk's arithmetic alive
         float keep = 0.f;
 #pragma unroll
@@ -412,7 +414,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
     }
 #endif
     // list entries behind every pixel's last contributor: zero rows (for those that own a row)
-    for (uint32_t e = hi + tid; e < total; e += NT) {
+    for (uint32_t e = hi + tid; e < total && GSR_ABLATE != 6; e += NT) {  // (ablation 6: what the zero rows cost)
         const uint32_t id = point_list[r0 + e];
         const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
         const float4 q0 = rec[0], q2 = rec[2], q3 = rec[3];

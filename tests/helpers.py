@@ -196,13 +196,16 @@ def _assert_culled_lists(ex, st):
 #     relative), so their result may differ from a double sum by ~2e-6 * sum|terms| whatever the order;
 #   stage 2, the per-Gaussian chain (K9 + K10: conic -> cov2D -> cov3D -> scale / rotation, mean projection, SH): the HIP outputs
 #     against oracle.chain_backward evaluated ON THE HIP KERNEL'S OWN SUMS.  Same inputs, same fp32 expression order, no FMA contraction
-#     on either side: the only differences are the last-bit ones of division / sqrt sequences, so the bar is tight and needs no
-#     conditioning term even for 500:1 needles:     |got - want| <= CHAIN_RTOL * (|want| + largest |want| of that Gaussian's tensor row)
-# No per-tensor scale, no blanket exception, no noise term.
+#     on either side, correctly rounded division / sqrt on both: the outputs are BIT-IDENTICAL -- measured over the whole GPU suite
+#     (292 tests: cfg2 / cfg3 / cfg4, 500:1 needles, the raw-parameter operator; gpurun_out/grad_worst.json) -- and the bar says so:
+#     CHAIN_RTOL = 0, i.e. got == want for every element, 500:1 needles included.
+# Measured (profiles/r04_grad_error.json, cfg2 camera 0; gpurun_out/grad_worst.json, whole suite): stage 1's worst |err| / tolerance was
+# 0.076 on cfg2 and 0.124 over the suite with GRAD_COND = 4e-6; the coefficient is now 1e-6 (2x the measured worst if the tolerance of
+# the worst element were its cond term alone).  No per-tensor scale, no blanket exception, no noise term.
 GRAD_ATOL = 1e-4
 GRAD_RTOL = 1e-4
-GRAD_COND = 4e-6
-CHAIN_RTOL = 1e-5
+GRAD_COND = 1e-6
+CHAIN_RTOL = 0.0
 GRAD_TOL = GRAD_ATOL
 BLEND_KEYS = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors")
 CHAIN_KEYS = ("dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")

@@ -41,7 +41,7 @@ def main():
     for v in stats.values():
         v.pop("worst", None)
     res = dict(workload=f"{name}: {cfg['P']} Gaussians, {cfg['W']}x{cfg['H']}, camera 0, N(0,1) dL/dcolor (seed 1)", R=int(ctx["R"]),
-               bar="stage 1: 1e-4 + 1e-4|want| + 4e-6 cond; stage 2: 1e-5 (|want| + row max)", tensors=stats)
+               bar="stage 1: 1e-4 + 1e-4|want| + 1e-6 cond; stage 2: bit-exact", tensors=stats)
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, v in stats.items():
         print(k, {a: (round(b, 8) if isinstance(b, float) else b) for a, b in v.items()})
