@@ -65,6 +65,7 @@ struct StageTimer {
 // ~50 us of GPU idle time per step) the prefix-sum kernel publishes R, tagged with a sequence number, in host-mapped
 // pinned memory and the host polls that word.
 constexpr int kMailSlots = 64;
+// slots kMailSlots, kMailSlots + 1 of the pinned words: the long-list hint of the tile binning (binning.hip, mid_hint_publish)
 struct Mailbox { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; };
 constexpr int kMailDevices = 64;  // more devices than that: the forward falls back to memcpy + stream sync
 Mailbox g_mail[kMailDevices];
@@ -80,9 +81,9 @@ bool mailbox_acquire(unsigned long long** host_slot, unsigned long long** dev_sl
     if (!m.host) {
         void* h = nullptr;
         void* d = nullptr;
-        if (hipHostMalloc(&h, kMailSlots * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipHostMalloc(&h, (kMailSlots + 1) * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return false; }
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return false; }
-        memset(h, 0, kMailSlots * sizeof(unsigned long long));
+        memset(h, 0, (kMailSlots + 1) * sizeof(unsigned long long));
         m.host = (unsigned long long*)h;
         m.dev = (unsigned long long*)d;
     }
@@ -90,6 +91,29 @@ bool mailbox_acquire(unsigned long long** host_slot, unsigned long long** dev_sl
     *host_slot = m.host + (s % kMailSlots);
     *dev_slot = m.dev + (s % kMailSlots);
     *seq = s;
+    return true;
+}
+
+// The long-list hint of this device (two 32-bit words behind the mailbox slots) and this call's frame number.  launch_mid = false only
+// when the hint is there, an earlier frame has reported, and none of the last 2^20 frames had a list of more than 2048 entries (a scene
+// that shows such a list once keeps the kernel for good: the in-kernel fallback costs milliseconds, the empty launch ~2 us).
+uint32_t g_bin_seq = 0;
+bool mid_hint_acquire(uint32_t** hint_dev, uint32_t* seq, bool* launch_mid)
+{
+    *hint_dev = nullptr; *seq = 0; *launch_mid = true;
+    int dev = 0;
+    const int mode = gsr_variant("MID_HINT", 1);  // 0: always launch the kernel, 1: by the hint, 2: never (tests of the in-kernel fallback)
+    if (mode == 2) *launch_mid = false;
+    if (mode != 1 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMailDevices) return false;
+    std::lock_guard<std::mutex> lk(g_mail_mu);
+    const Mailbox& m = g_mail[dev];
+    if (!m.host) return false;  // (created by the geometry phase's mailbox_acquire)
+    const volatile uint32_t* h = reinterpret_cast<const volatile uint32_t*>(m.host + kMailSlots);
+    const uint32_t s = ++g_bin_seq;
+    const uint32_t done = h[0], mid = h[1];
+    *hint_dev = reinterpret_cast<uint32_t*>(m.dev + kMailSlots);
+    *seq = s;
+    *launch_mid = done == 0u || (mid != 0u && s - mid <= (1u << 20));
     return true;
 }
 
@@ -359,10 +383,14 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
                 hipMemsetAsync(g + G.band_count, 0, GSR_BAND_COUNTERS * 4, s);
                 launch_render_head(P, W, H, geom_buffer, binning_buffer, s);
             }
+            uint32_t* hint = nullptr;
+            uint32_t hint_seq = 0;
+            bool launch_mid = true;
+            mid_hint_acquire(&hint, &hint_seq, &launch_mid);
             StageTimer t(GSR_STAGE_SORT, s, false);
             gsr_launch_tile_binning_tail(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
                                          (uint32_t*)(b + B.order), ranges, (const uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), ka, va,
-                                         gsr_variant("KEYS", 0) ? kb : nullptr, s);
+                                         gsr_variant("KEYS", 0) ? kb : nullptr, hint, hint_seq, launch_mid, s);
             point_list = va;
         } else {
         {

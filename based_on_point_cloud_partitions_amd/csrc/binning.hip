@@ -74,6 +74,17 @@ __device__ __forceinline__ void list_append(bool is_long, uint32_t tile, uint32_
 #define GSR_BIN_ABLATE 0
 #endif
 
+// What the host learns about a frame WITHOUT waiting for it (two words of host-mapped pinned memory, read at the start of a later
+// call): hint[0] = number of the last frame whose scatter ran, hint[1] = number of the last frame that had a list of more than
+// BUCKET_CAP entries.  A frame whose recent predecessors had none does not launch tile_sort_mid_kernel (an empty launch still
+// costs its ~5 us boundary); should such a list turn up anyway, tile_sort_small_kernel sorts it with the slow in-place network.
+__device__ __forceinline__ void mid_hint_publish(uint32_t* hint, uint32_t seq, bool first_band, bool has_mid)
+{
+    if (!hint) return;
+    if (first_band) __hip_atomic_store(hint, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (has_mid) __hip_atomic_store(hint + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct SliceRect {
     uint32_t mnx, mny, mxx, mxy, dbits;
     unsigned long long mask;  // reachable tiles of the rectangle (bit = row-major position); ~0 = all (no culling, or > 64 tiles)
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(256) tile_colscan_kernel(int T, int nslices, u
 __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int gpb, int gx, int gy, int T, int cull, const float* __restrict__ splat,
                                                            const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
                                                            uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                           uint2* __restrict__ bins)
+                                                           uint2* __restrict__ bins, uint32_t* hint, uint32_t hint_seq)
 {
     extern __shared__ uint32_t s_cur[];
     __shared__ uint32_t wtot[16];
@@ -192,7 +203,10 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_kernel(int P, int 
             list_append(n > (uint32_t)BUCKET_CAP, (uint32_t)i, &s_nlong[1], order + GSR_MID_LIST(T));
         }
         __syncthreads();
-        if (threadIdx.x == 0) { order[GSR_LONG_COUNT(T)] = s_nlong[0]; order[GSR_MID_COUNT(T)] = s_nlong[1]; }
+        if (threadIdx.x == 0) {
+            order[GSR_LONG_COUNT(T)] = s_nlong[0]; order[GSR_MID_COUNT(T)] = s_nlong[1];
+            mid_hint_publish(hint, hint_seq, true, s_nlong[1] != 0u);
+        }
         if (threadIdx.x < 256) order[GSR_CLASS_HIST(T) + threadIdx.x] = s_cls[threadIdx.x];
     }
     const int first = blockIdx.x * gpb, last = min(P, first + gpb);
@@ -411,7 +425,7 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_banded_kernel(int 
                                                                              const uint32_t* __restrict__ band_list,
                                                                              const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
                                                                              uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                                             uint2* __restrict__ bins)
+                                                                             uint2* __restrict__ bins, uint32_t* hint, uint32_t hint_seq)
 {
     extern __shared__ uint32_t s_cur[];
     __shared__ uint32_t wtot[16], woth[16];
@@ -478,7 +492,10 @@ __global__ void __launch_bounds__(SLICE_THREADS) tile_scatter_banded_kernel(int 
         chunk_base += chunk_total;
         __syncthreads();
     }
-    if (sidx == 0 && threadIdx.x == 0) { order[GSR_LONG_COUNT(T) + b] = s_nlong[0]; order[GSR_MID_COUNT(T) + b] = s_nlong[1]; }
+    if (sidx == 0 && threadIdx.x == 0) {
+        order[GSR_LONG_COUNT(T) + b] = s_nlong[0]; order[GSR_MID_COUNT(T) + b] = s_nlong[1];
+        mid_hint_publish(hint, hint_seq, b == 0, s_nlong[1] != 0u);
+    }
     if (sidx == 0 && threadIdx.x < 256) order[GSR_CLASS_HIST(T) + b * 256 + threadIdx.x] = s_cls[threadIdx.x];
     if (GSR_BIN_ABLATE >= 2 && !(have && r.dbits == 0x12345678u)) have = false;  // (keeps the first loads alive)
     while (have) {
@@ -817,9 +834,9 @@ union TileSortLds {
 
 __global__ void __launch_bounds__(256) tile_sort_small_kernel(int T, int n_long, int nbl, int seg, uint32_t* __restrict__ order,
                                                               const uint32_t* __restrict__ ranges,
-                                                              const unsigned long long* __restrict__ bins,
+                                                              const unsigned long long* bins,
                                                               uint32_t* __restrict__ point_list,
-                                                              unsigned long long* __restrict__ keys_sorted)
+                                                              unsigned long long* __restrict__ keys_sorted, int mid_fallback)
 {
     __shared__ TileSortLds L;
     if ((int)blockIdx.x < nbl) {
@@ -841,6 +858,26 @@ __global__ void __launch_bounds__(256) tile_sort_small_kernel(int T, int n_long,
             else bucket_sort_tile<8, 256, BUCKET_CAP>(L.whole, tile, r0, n, N, bins, point_list, keys_sorted);
             __syncthreads();  // the LDS image is reused by the next list
         }
+        // tile_sort_mid_kernel was not launched (no list that long in the recent frames, see mid_hint_publish) and this frame has
+        // one after all: the normalized bitonic network in place in HBM -- slow (milliseconds on a dense scene), one frame long
+        if (mid_fallback)
+            for (uint32_t k = blockIdx.x - (uint32_t)nbl;; k += (uint32_t)n_long) {
+                uint32_t tile;
+                if (!listed_tile(order + GSR_MID_COUNT(T), order + GSR_MID_LIST(T), nbl, seg, k, tile)) break;
+                const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+                const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
+                const uint32_t n = r1 - r0;
+                uint32_t N = 1;
+                while (N < n) N <<= 1;
+                unsigned long long* sg = const_cast<unsigned long long*>(bins) + r0;
+                bitonic_sort_block<false>(sg, n, N);
+                for (uint32_t q = threadIdx.x; q < n; q += 256) {
+                    const unsigned long long key = sg[q];
+                    point_list[r0 + q] = (uint32_t)key;
+                    if (keys_sorted) keys_sorted[r0 + q] = ((unsigned long long)tile << 32) | (key >> 32);
+                }
+                __syncthreads();
+            }
         return;
     }
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -979,7 +1016,7 @@ void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint3
 
 void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
                                   uint32_t* ranges, const uint32_t* band_count, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list,
-                                  uint64_t* keys_sorted, hipStream_t s)
+                                  uint64_t* keys_sorted, uint32_t* hint, uint32_t hint_seq, bool launch_mid, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int T = gx * gy;
@@ -988,21 +1025,23 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
     if (band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_)) {
         const uint32_t* band_list = band_mem + GSR_BAND_COUNTERS;
         hipLaunchKernelGGL(tile_scatter_banded_kernel, dim3(G.nb * BAND_SLICES), dim3(SLICE_THREADS), (size_t)G.tmax * 4, s, P, G, splat,
-                           band_count, band_list, table, totals, ranges, order, reinterpret_cast<uint2*>(bins));
+                           band_count, band_list, table, totals, ranges, order, reinterpret_cast<uint2*>(bins), hint, hint_seq);
     } else {
         int gpb;
         const int ns = gsr_tile_slices(P, &gpb);
         const size_t lds = (size_t)(T < TCHUNK ? T : TCHUNK) * 4;
         hipLaunchKernelGGL(tile_scatter_kernel, dim3(ns), dim3(SLICE_THREADS), lds, s, P, gpb, gx, gy, T, G.cull, splat, table, totals, ranges,
-                           order, reinterpret_cast<uint2*>(bins));
+                           order, reinterpret_cast<uint2*>(bins), hint, hint_seq);
     }
     // long-list segments: one per band (banded scatter) or one for the image
     const bool banded = band_mem && gsr_band_geometry(gx, gy, &nb_, &bh_);
     const int nbl = banded ? G.nb : 1, seg = banded ? G.tmax : 0;
     const int n_long = T < 1024 ? T : 1024;
     hipLaunchKernelGGL(tile_sort_small_kernel, dim3(nbl + n_long + (T + 3) / 4), dim3(256), 0, s, T, n_long, nbl, seg, order, ranges,
-                       reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
-    hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, nbl, seg, order, ranges,
+                       reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted),
+                       launch_mid ? 0 : 1);
+    if (launch_mid)
+        hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, nbl, seg, order, ranges,
                        reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
 }
 

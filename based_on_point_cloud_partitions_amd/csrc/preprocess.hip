@@ -242,6 +242,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float
     __shared__ uint32_t wsum[4], rsum[4];
     if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = v; rsum[threadIdx.x >> 6] = r; }
     __syncthreads();
+    // (Folding the block scan in here -- the workgroup that finishes last scans, found with a device-scope ticket counter -- was built
+    // and measured in round 4: with a release fence per workgroup this kernel went 0.039 -> 0.166 ms (every fence writes back the
+    // XCD's whole L2), with atomic stores of the two sums + s_waitcnt 0.039 + 0.008 -> 0.051 ms: 1,954 tickets on one address cost
+    // more than the launch boundary they save.  profiles/README.md.)
     if (threadIdx.x == 0) {
         a.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         a.row_block_sums[blockIdx.x] = rsum[0] + rsum[1] + rsum[2] + rsum[3];

@@ -132,6 +132,24 @@ def test_very_long_tile_lists_use_the_in_place_sort_path():
     assert ((ln > 1024) & (ln <= 4096)).any()
 
 
+def test_lists_beyond_2048_entries_without_the_mid_kernel():
+    """The frame-late hint of the tile binning (binning.hip, mid_hint_publish) leaves tile_sort_mid_kernel out when no recent frame
+    had a list of more than 2048 entries; a frame that has one after all is sorted by tile_sort_small_kernel's in-place network.
+    GSR_MID_HINT=2 forces that path; =1 (default) after frames without long lists takes it by itself on the first long frame."""
+    from based_on_point_cloud_partitions_amd import _lib
+
+    try:
+        _lib.set_variant("MID_HINT", 2)
+        st, _ = _fwd_bwd(P=100_000, W=128, H=128, focal=80.0, seed=14, scale_lo=0.004, scale_hi=0.03)
+        ln = st["ranges"][:, 1] - st["ranges"][:, 0]
+        assert (ln > 8192).any() and ((ln > 2048) & (ln <= 8192)).any()
+    finally:
+        _lib.set_variant("MID_HINT", 1)
+    # by the hint itself (whatever the earlier tests of this process left in it): long lists, then short ones
+    _fwd_bwd(P=100_000, W=128, H=128, focal=80.0, seed=15, scale_lo=0.004, scale_hi=0.03)
+    _fwd_bwd(P=3000, W=160, H=128, focal=100.0, seed=1, scale_lo=0.01, scale_hi=0.15)
+
+
 def test_many_equal_depths_tie_break_by_index():
     # exact duplicates of positions -> identical depth bits: ties must come out in ascending Gaussian index (the stable
     # sort's emission order); also drives the per-tile bucket sort into its overflow (bitonic) path
