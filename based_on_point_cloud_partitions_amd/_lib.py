@@ -74,6 +74,7 @@ PROTOTYPES = {
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),
     "gsr_debug_capture_sums": (c_int, [c_void_p]),
+    "gsr_debug_knn_counter": (c_int, [c_void_p]),
     "gsr_build_info": (ctypes.c_char_p, []),
     "gsr_set_variant": (c_int, [ctypes.c_char_p, c_int]),
     "gsr_get_variant": (c_int, [ctypes.c_char_p, c_int]),
@@ -147,6 +148,12 @@ def capture_sums(tensor):
     """Test hook (two-stage gradient check): while set, every backward also stores the per-Gaussian blend sums its chain consumes
     into `tensor` ([P,12] float32 on the device); None switches it off."""
     check(load().gsr_debug_capture_sums(None if tensor is None else tensor.data_ptr()), "gsr_debug_capture_sums")
+
+
+def knn_counter(tensor):
+    """Measurement hook: while set, distCUDA2 adds the number of candidate distances it evaluates to `tensor` (one int64 on the
+    device, zeroed by the caller); None switches it off."""
+    check(load().gsr_debug_knn_counter(None if tensor is None else tensor.data_ptr()), "gsr_debug_knn_counter")
 
 
 def set_variant(name, value):

@@ -14,6 +14,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 float* g_capture_sums = nullptr;  // gsr_debug_capture_sums
+unsigned long long* g_knn_evals = nullptr;  // gsr_debug_knn_counter
 
 int fail(int code, const char* fmt, const char* a = "")
 {
@@ -808,7 +809,7 @@ int gsr_knn_mean_dist2(int P, const float* points, float* out, void* scratch, si
 {
     if (P == 0) return 0;
     if (!points || !out || !scratch) return fail(-1, "NULL required pointer");
-    if (gsr_knn_run(P, points, out, scratch, scratch_bytes, (hipStream_t)stream) != 0) return fail(-3, "knn scratch too small");
+    if (gsr_knn_run(P, points, out, scratch, scratch_bytes, g_knn_evals, (hipStream_t)stream) != 0) return fail(-3, "knn scratch too small");
     return check_hip("knn_mean_dist2");
 }
 
@@ -857,6 +858,12 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
 int gsr_debug_capture_sums(float* sums)
 {
     g_capture_sums = sums;
+    return 0;
+}
+
+int gsr_debug_knn_counter(uint64_t* counter)
+{
+    g_knn_evals = reinterpret_cast<unsigned long long*>(counter);
     return 0;
 }
 

@@ -276,7 +276,7 @@ void gsr_launch_compact_rows(int P, const uint8_t* keep, const uint32_t* block_o
                              hipStream_t s);
 
 size_t gsr_knn_scratch_layout_bytes(int P);
-int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
+int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, unsigned long long* evals, hipStream_t s);
 
 // ---- device helpers ----
 #ifdef __HIPCC__

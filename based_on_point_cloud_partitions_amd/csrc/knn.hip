@@ -81,13 +81,16 @@ __global__ void __launch_bounds__(256) minmax_partial_kernel(int P, const float*
         partial[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
+// one wave: every lane takes every 64th partial row, then six wave reductions (round 3: six threads walked all rows one dependent
+// load after the other -- 51 us for a kilobyte-sized reduce)
 __global__ void __launch_bounds__(64) minmax_final_kernel(int nb, const float* __restrict__ partial, float* __restrict__ minmax)
 {
-    if (threadIdx.x < 6) {
-        float v = 0.f;
-        for (int b = 0; b < nb; b++) v = threadIdx.x < 3 ? fminf(v, partial[b * 6 + threadIdx.x]) : fmaxf(v, partial[b * 6 + threadIdx.x]);
-        minmax[threadIdx.x] = v;
-    }
+    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < nb; b += 64)
+        for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], partial[b * 6 + c]); mx[c] = fmaxf(mx[c], partial[b * 6 + 3 + c]); }
+    for (int c = 0; c < 3; c++) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; c++) { minmax[c] = mn[c]; minmax[3 + c] = mx[c]; }
 }
 
 __device__ __forceinline__ uint32_t prep_morton(uint32_t x)  // simple_knn.cu:45-52
@@ -186,9 +189,10 @@ __device__ __forceinline__ void update3(float qx, float qy, float qz, float cx, 
 template <int BOX>
 __global__ void __launch_bounds__(256) knn_kernel(int P, uint32_t num_boxes, int group, const float4* __restrict__ sorted,
                                                   const float* __restrict__ boxes, const float* __restrict__ supers,
-                                                  float* __restrict__ out)
+                                                  float* __restrict__ out, unsigned long long* __restrict__ evals)
 {
     __shared__ float s_x[BOX], s_y[BOX], s_z[BOX];
+    uint32_t my_evals = 0;  // candidate distances this query evaluated (only summed up when a counter was handed in: bench.py)
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool valid = idx < P;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -227,6 +231,7 @@ __global__ void __launch_bounds__(256) knn_kernel(int P, uint32_t num_boxes, int
             __syncthreads();
             if (want) {
                 const int self = idx - base;  // position of this query inside the box, if it is in it
+                my_evals += (uint32_t)cnt;
                 for (int k = 0; k < cnt; k++) {
                     if (k == self) continue;
                     update3(qx, qy, qz, s_x[k], s_y[k], s_z[k], b0, b1, b2);
@@ -236,13 +241,19 @@ __global__ void __launch_bounds__(256) knn_kernel(int P, uint32_t num_boxes, int
         }
     }
     if (valid) out[orig] = (b0 + b1 + b2) / 3.0f;
+    if (evals) {
+        unsigned long long e = my_evals;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(evals, e);
+    }
 }
 
 }  // namespace
 
 size_t gsr_knn_scratch_layout_bytes(int P) { return knn_layout(P).bytes; }
 
-int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s)
+int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, unsigned long long* evals, hipStream_t s)
 {
     if (P <= 0) return 0;
     const KnnLayout L = knn_layout(P);
@@ -272,7 +283,7 @@ int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t sc
         const uint32_t nb = (uint32_t)((P + (B) - 1) / (B));                                                                \
         hipLaunchKernelGGL(box_minmax_kernel<B>, dim3(nb), dim3(256), 0, s, P, sorted, boxes);                              \
         hipLaunchKernelGGL(super_minmax_kernel, dim3((nb / group + 256) / 256), dim3(256), 0, s, nb, group, boxes, supers);  \
-        hipLaunchKernelGGL(knn_kernel<B>, dim3((P + 255) / 256), dim3(256), 0, s, P, nb, group, sorted, boxes, supers, out); \
+        hipLaunchKernelGGL(knn_kernel<B>, dim3((P + 255) / 256), dim3(256), 0, s, P, nb, group, sorted, boxes, supers, out, evals); \
     }
     const int group = max(1, gsr_variant("KNN_GROUP", 32));
     float* supers = (float*)(base + L.supers);

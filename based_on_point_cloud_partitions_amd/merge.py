@@ -43,19 +43,31 @@ def crop_mask(xyz, box):
     return mask
 
 
+def _ordered_int(col):
+    """float32 column -> int32 with the same order under signed comparison (-0.0 counted as +0.0, as float comparison does)."""
+    i = (col + 0.0).contiguous().view(torch.int32)  # x + 0.0 turns -0.0 into +0.0
+    return i ^ ((i >> 31) & 0x7FFFFFFF)
+
+
 def dedup_first_lexicographic(rows):
     """np.unique(rows[:, :3], axis=0, return_index=True) semantics applied to whole rows: output sorted by (x,y,z),
-    for equal xyz the row with the smallest original index survives."""
+    for equal xyz the row with the smallest original index survives.
+    Two stable sorts of integer keys -- z, then (x, y) packed into one int64 -- over the three contiguous coordinate columns, and ONE
+    gather of the surviving 236-byte rows (round 3: three stable float sorts, each behind a strided gather of a column of the
+    [N, 59] block: 206 ms for 500k rows on the MI355X)."""
     n = rows.shape[0]
     if n == 0:
         return rows
-    order = torch.arange(n, device=rows.device)
-    for col in (2, 1, 0):  # stable sorts from the least significant key
-        _, idx = torch.sort(rows[order, col], stable=True)
-        order = order[idx]
-    s = rows[order, :3]
+    xyz = rows[:, :3].t().contiguous()  # [3, n]: coalesced columns
+    ix, iy, iz = _ordered_int(xyz[0]), _ordered_int(xyz[1]), _ordered_int(xyz[2])
+    _, order = torch.sort(iz, stable=True)
+    # (x, y) as one signed 64-bit key: x in the high half as it is, y in the low half shifted into 0 .. 2^32 - 1
+    kxy = (ix.to(torch.int64) << 32) | (iy.to(torch.int64) + 2147483648)
+    _, idx = torch.sort(kxy[order], stable=True)
+    order = order[idx]
+    sx, sy, sz = ix[order], iy[order], iz[order]
     first = torch.ones(n, dtype=torch.bool, device=rows.device)
-    first[1:] = (s[1:] != s[:-1]).any(dim=1)
+    first[1:] = (sx[1:] != sx[:-1]) | (sy[1:] != sy[:-1]) | (sz[1:] != sz[:-1])
     return rows[order[first]]
 
 

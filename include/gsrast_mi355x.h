@@ -217,6 +217,10 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
  * dL_dopacity / dL_dcolor, rasterize_points.cu:151-159); rows of culled Gaussians are not written.  NULL switches it off. */
 int gsr_debug_capture_sums(float* sums);
 
+/* Measurement hook (bench.py's roofline_knn): while `counter` (a device uint64, zeroed by the caller) is non-NULL, gsr_knn_mean_dist2
+ * adds to it the number of candidate distances its queries evaluate.  NULL switches it off. */
+int gsr_debug_knn_counter(uint64_t* counter);
+
 /* What this binary was built with: "abi=<n> ablate=<GSR_ABLATE> bin_ablate=<GSR_BIN_ABLATE> extra=[<make EXTRA=...>]".  The two
  * ablation macros are timing experiments that produce wrong results on purpose; a shipped library reports 0 for both and an
  * empty extra (tests/test_abi.py checks the built .so; bench.py prints the string). */
