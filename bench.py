@@ -381,11 +381,14 @@ def main():
     torch.cuda.set_device(dev)
     # The collective library: RCCL (torch's "nccl" backend on ROCm).  Two ranks cannot share one GPU under RCCL, so a rehearsal of
     # N ranks on fewer GPUs falls back to gloo and says so (`collective_backend`).  At N = 1 a world-size-1 RCCL group is brought up
-    # as well (--dist auto): the same librccl init / all_gather_into_tensor / all_reduce / barrier entry points the N > 1 run uses
-    # execute on this GPU, and every `dist` branch below is the one an 8-GPU run takes.
-    dist, dist_error = None, None
+    # as well (--dist auto) -- the same librccl init / all_gather_into_tensor / all_reduce / barrier entry points the N > 1 run
+    # uses execute on this GPU, through the same `dist` branches below -- but only AFTER the timed region: there is no other rank to
+    # align with, and the first process on a fresh box that initialises RCCL runs 5-10 % slower for the next seconds (librccl's
+    # code objects page in behind it: 0.697 ms/step in the spin-up, 0.735 / 0.768 in the timed region right after, two boxes).
+    dist_state = {"dist": None, "error": None, "ranks_seen": [0]}
     backend = os.environ.get("GSR_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
-    if args.dist == "on" or world > 1 or (args.dist == "auto" and backend == "nccl"):
+
+    def init_dist():
         import datetime
 
         import torch.distributed as dist_
@@ -398,18 +401,20 @@ def main():
                 dist_.init_process_group("nccl", device_id=dev, **kw)
             else:
                 dist_.init_process_group(backend, **kw)
-            dist = dist_
         except Exception as exc:  # noqa: BLE001 -- only tolerable at world 1, where no exchange is needed
             if world > 1 or args.dist == "on":
                 raise
-            dist_error = f"{type(exc).__name__}: {exc}"
-    # what the collective library itself saw: every rank contributes its number through one all-gather
-    ranks_seen = [0]
-    if dist is not None:
-        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+            dist_state["error"] = f"{type(exc).__name__}: {exc}"
+            return None
+        # what the collective library itself saw: every rank contributes its number through one all-gather
+        cdev = dev if dist_.get_backend() == "nccl" else "cpu"
         seen = torch.full((world,), -1, dtype=torch.int64, device=cdev)
-        dist.all_gather_into_tensor(seen, torch.tensor([rank], dtype=torch.int64, device=cdev))
-        ranks_seen = sorted(int(v) for v in seen.tolist())
+        dist_.all_gather_into_tensor(seen, torch.tensor([rank], dtype=torch.int64, device=cdev))
+        dist_state["ranks_seen"] = sorted(int(v) for v in seen.tolist())
+        dist_state["dist"] = dist_
+        return dist_
+
+    dist = init_dist() if world > 1 else None
 
     cfg = syn.CONFIGS[args.config]
     P, W, H = cfg["P"], cfg["W"], cfg["H"]
@@ -512,6 +517,12 @@ def main():
     # steps settle at 0.700 ms/step, a 48-step region timed right after an idle gap reads 0.735.  So batches of 64 steps run until four in
     # a row bring no improvement of 0.5 % (at least 0.5 s, at most --spinup-ms), and the timed region starts right behind the last one.
     spinup = None
+    # N > 1: at least 2 s -- the process group came up before the warm-up, and the seconds behind librccl's first use are slow on a
+    # fresh box (see init_dist above); the collectives the timed region uses are warmed here too
+    min_spin = 0.5 if world == 1 else min(2.0, 1e-3 * args.spinup_ms)
+    if dist is not None:
+        for _ in range(3):
+            dist.barrier()
     if args.spinup_ms > 0:
         t_spin, k, best, flat, batches = time.perf_counter(), 0, float("inf"), 0, []
         while 1e3 * (time.perf_counter() - t_spin) < args.spinup_ms:
@@ -526,7 +537,7 @@ def main():
                 best, flat = dt, 0
             else:
                 flat += 1
-            if flat >= 4 and time.perf_counter() - t_spin > 0.5:
+            if flat >= 4 and time.perf_counter() - t_spin > min_spin:
                 break
         spinup = {"steps": k, "ms": round(1e3 * (time.perf_counter() - t_spin), 1), "first_batch_ms_per_step": batches[0],
                   "last_batch_ms_per_step": batches[-1]}
@@ -555,6 +566,8 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed_incl_barrier = time.perf_counter() - t0
+    if world == 1 and (args.dist == "on" or (args.dist == "auto" and backend == "nccl")):
+        dist = init_dist()  # N = 1: the world-size-1 RCCL group, behind the timed region (see above)
     gc.enable()
     _lib.profile_enable(False)
     timed = _lib.profile_collect() if use_timers else {}
@@ -745,8 +758,11 @@ def main():
                                      "unit": "GB/s", "frac": round(120 * P / 1e9 / (knn_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                              "note": "whole distCUDA2 call (8 launches incl. the Morton sort); exact 3-NN: 64-point boxes in groups of 32, "
                                      "a box no query of the workgroup can reject is scanned from LDS"},
-            "rccl_world_size": len(ranks_seen), "rccl_ranks_seen": ranks_seen,
-            "collective_backend": (dist.get_backend() if dist is not None else None), "collective_init_error": dist_error,
+            "rccl_world_size": len(dist_state["ranks_seen"]), "rccl_ranks_seen": dist_state["ranks_seen"],
+            "collective_backend": (dist.get_backend() if dist is not None else None), "collective_init_error": dist_state["error"],
+            "collective_init": ("before the warm-up (N > 1: the timed region is bracketed by its barriers)" if world > 1 else
+                                "after the timed region (N = 1: no rank to align with; the later collectives -- all-reduce of the "
+                                "timing, merge all-gather, evaluation all-reduce, barrier -- run through it)"),
             "merge": {"world_size": ev["world_size"], "rows_per_rank_after_crop": ev["counts"], "merged_rows": merged_rows,
                       "merge_allgather_ms": round(ev["merge_allgather_ms"], 3),
                       "allgather_bytes_per_rank": int(max(ev["counts"]) * merge.ROW * 4),
