@@ -68,8 +68,23 @@ from based_on_point_cloud_partitions_amd import synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PLAIN_CYCLES = 2.4  # SIMD cycles per plain wave64 VOP2/VOP3 instruction with 4-8 waves per SIMD (profiles/r01_valu_cost.txt)
-# the VALU-issue-bound kernels and the mean price-list cycles of one of their VALU instructions (the mix per blend event)
-VALU_BOUND = {"render_backward": 3.0, "render_forward": 2.6}
+VALU_BOUND = ("render_backward", "render_forward")  # the VALU-issue-bound kernels
+
+
+def price_list_cycles(v):
+    """Mean SIMD cycles per VALU instruction of a kernel from its PMC instruction-class counts (profiles/pmc_traffic.json) and the
+    measured price list of gfx950 (tools/valu_cost.hip): the counted plain classes (f32 add / mul / fma, int32) 2.4 cycles, transcendentals
+    (v_exp, v_rcp) 8.5, everything the class counters do not name -- compares, selects, lane reads, permlane swaps, converts, moves --
+    4.3.  DPP-modified adds are counted as plain adds and some of the unnamed instructions are plain moves, so this is an estimate of the
+    kernel's issue time, not a bound; None when the class counters are not on file."""
+    need = ("sq_insts_valu", "sq_insts_valu_add_f32", "sq_insts_valu_mul_f32", "sq_insts_valu_fma_f32", "sq_insts_valu_int32",
+            "sq_insts_valu_trans_f32")
+    if not all(k in v for k in need):
+        return None
+    plain = v["sq_insts_valu_add_f32"] + v["sq_insts_valu_mul_f32"] + v["sq_insts_valu_fma_f32"] + v["sq_insts_valu_int32"]
+    trans = v["sq_insts_valu_trans_f32"]
+    other = max(v["sq_insts_valu"] - plain - trans, 0.0)
+    return (2.4 * plain + 8.5 * trans + 4.3 * other) / v["sq_insts_valu"]
 FP32_VALU_PEAK_TFLOPS = 157.3
 
 
@@ -566,8 +581,6 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed_incl_barrier = time.perf_counter() - t0
-    if world == 1 and (args.dist == "on" or (args.dist == "auto" and backend == "nccl")):
-        dist = init_dist()  # N = 1: the world-size-1 RCCL group, behind the timed region (see above)
     gc.enable()
     _lib.profile_enable(False)
     timed = _lib.profile_collect() if use_timers else {}
@@ -615,6 +628,15 @@ def main():
     torch.cuda.synchronize()
     knn_ms = round(1e3 * (time.perf_counter() - tk) / 5, 3)
 
+    if world == 1 and (args.dist == "on" or (args.dist == "auto" and backend == "nccl")):
+        # N = 1: the world-size-1 RCCL group comes up here -- behind the timed region and every other timing of this script -- and the
+        # collectives of an N > 1 run follow through it: all-reduce (MAX) of the timing, merge all-gathers, evaluation all-reduce, barrier
+        dist = init_dist()
+        if dist is not None:
+            t = torch.tensor([elapsed, elapsed_incl_barrier], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, elapsed_incl_barrier = (float(v) for v in t.tolist())
+            dist.barrier()
     # config 5 (BASELINE.json configs[4]): seamless merge of the partitions + evaluation of the merged scene, once, untimed w.r.t.
     # the headline.  Every rank crops its partition to its origin box (open sides where it has no neighbour), ONE all-gather
     # of the padded [maxN, 59] blocks (RCCL over xGMI at N > 1), np.unique-style dedup, then each rank renders its own
@@ -626,6 +648,7 @@ def main():
         bx0, bx1, by0, by1 = syn.partition_origin_box(r_, world)
         boxes.append((bx0, by0, bx1, by1))
     with torch.no_grad():
+        merge.dedup_first_lexicographic(torch.rand(4096, merge.ROW, device=dev))  # (loads the sort kernels: dedup_ms is the algorithm's time)
         raw_block = merge.pack_block(xyz.detach(), shs.detach()[:, :1], shs.detach()[:, 1:],
                                      torch.logit(opac.detach().clamp(1e-6, 1 - 1e-6)), torch.log(scales.detach()), rots.detach())
         views = [syn.ring_cameras(cfg["cameras"], W, H, cfg["focal"],
@@ -684,6 +707,9 @@ def main():
                 # two is VALU-issue bound.
                 k["valu_insts"] = int(v["sq_insts_valu"])
                 k["simd_cycles_per_valu_inst"] = round(1024 * 2.4e9 * k["avg_ms"] * 1e-3 / v["sq_insts_valu"], 2)
+                pl = price_list_cycles(v)
+                if pl is not None:
+                    k["price_list_cycles_per_valu_inst"] = round(pl, 2)
             if "hbm_bytes" in v:
                 k["hbm_traffic_MB"] = round(v["hbm_bytes"] / 1e6, 1)
         kernels.sort(key=lambda k: -k["avg_ms"])
@@ -701,14 +727,15 @@ def main():
                 # priced against is the chip's VALU issue rate.  `peak` = 1024 SIMDs x 2.4 GHz / 2.4 cycles per plain wave64 VOP
                 # (tools/valu_cost.hip, profiles/r01_valu_cost.txt), `achieved` = VALU wave-instructions retired per second (PMC count
                 # / this run's average launch duration): `frac` is the share of the kernel's SIMD cycles that issuing its VALU
-                # instructions at the PLAIN price needs.  `frac_price_list` prices the kernel's instruction mix (compares / selects /
-                # DPP at 4.3 cycles, v_exp / v_rcp / permlane swaps at 8.5; the mix is the one DESIGN.md §5 derives per blend event).
+                # instructions at the PLAIN price needs (a floor).  `frac_price_list` prices the kernel's measured instruction mix
+                # (price_list_cycles above).
                 rate = d["valu_insts"] / (d["avg_ms"] * 1e-3) / 1e9
                 peak = 1024 * 2.4 / VALU_PLAIN_CYCLES
+                pl = d.get("price_list_cycles_per_valu_inst")
                 roofline = {"kernel": d["kernel"], "bound": "valu_issue", "achieved": round(rate, 1), "peak": round(peak, 1),
                             "unit": "G wave-instr/s", "frac": round(rate / peak, 4),
-                            "frac_price_list": round(rate / peak * VALU_BOUND[d["kernel"]] / VALU_PLAIN_CYCLES, 4),
-                            "mean_cycles_per_inst_price_list": VALU_BOUND[d["kernel"]],
+                            "frac_price_list": round(rate / peak * pl / VALU_PLAIN_CYCLES, 4) if pl else None,
+                            "mean_cycles_per_inst_price_list": pl,
                             "valu_insts": d["valu_insts"], "simd_cycles_per_valu_inst": d["simd_cycles_per_valu_inst"],
                             "traffic": hbm["traffic"], "traffic_source": src, "avg_ms": d["avg_ms"], "hbm": hbm,
                             "note": "dominant kernel by time; VALU-issue-bound pair loop -- its HBM figures are under `hbm` (low by "

@@ -55,6 +55,20 @@ def main(d, out):
     import os
     sqp = f"{d}/sq_counter_collection.csv"
     sq = {c: load(sqp, c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES")} if os.path.exists(sqp) else {}
+    # instruction classes (separate passes sq3 / sq4 of tools/r4_collect.sh): what bench.py prices the VALU-bound kernels with
+    for extra, names in (("sq3", ("SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT")),
+                         ("sq4", ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_INT32"))):
+        ep = f"{d}/{extra}_counter_collection.csv"
+        if os.path.exists(ep):
+            sq.update({c: load(ep, c) for c in names})
+    # ... or, when the raw CSVs are gone, the per-kernel summary tools/r4_collect.sh keeps (sq_counters.json)
+    sj = f"{d}/sq_counters.json"
+    if os.path.exists(sj):
+        per_kernel = json.load(open(sj))
+        for c in ("SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
+                  "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
+            if c not in sq or not sq[c]:
+                sq[c] = {k.split("<")[0]: v[c] for k, v in per_kernel.items() if c in v}
     for c, per in sq.items():
         for k, st in STAGE.items():
             if binned and k in radix:

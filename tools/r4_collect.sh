@@ -18,7 +18,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out -o write -- python3 bench
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out -o sq -- python3 bench.py $Q > $out/sq.log 2>&1 || exit 5
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT --output-format csv -d $out -o sq3 -- python3 bench.py $Q > $out/sq3.log 2>&1 || echo "sq3 pass failed (counter set not available)"
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 --output-format csv -d $out -o sq4 -- python3 bench.py $Q > $out/sq4.log 2>&1 || echo "sq4 pass failed (counter set not available)"
-python3 profiles/pmc_to_json.py $out $out/pmc_traffic.json
 python3 - <<PY
 import csv,glob,collections,json
 res=collections.defaultdict(dict)
@@ -35,6 +34,7 @@ for tagf in ("sq","sq3","sq4"):
 json.dump(res,open("$out/sq_counters.json","w"),indent=1,sort_keys=True)
 for k,v in res.items(): print(k[:50].ljust(50)," ".join("%s=%.4g"%(a.replace("SQ_",""),b) for a,b in sorted(v.items())))
 PY
+python3 profiles/pmc_to_json.py $out $out/pmc_traffic.json
 for cfg in cfg1 cfg4; do python3 bench.py --config $cfg --no-cpu-baseline > $out/bench_$cfg.log 2>/dev/null; grep '^{' $out/bench_$cfg.log > $out/bench_$cfg.json; done
 python3 bench.py --order morton --no-cpu-baseline > $out/bench_morton.log 2>/dev/null; grep '^{' $out/bench_morton.log > $out/bench_morton.json
 python3 bench.py --full-step --steps 20 --warmup 4 --no-cpu-baseline > $out/bench_full.log 2>/dev/null; grep '^{' $out/bench_full.log > $out/bench_full_step.json
