@@ -71,7 +71,10 @@ int gsr_forward(int P, int D, int M, const float* background, const float* means
 /* CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:340-434) + the zero-initialised outputs of
  * RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-159): every output element is written.
  * Outputs: dL_dmeans2D[P][3], dL_dcolors[P][3], dL_dopacity[P], dL_dmeans3D[P][3], dL_dcov3D[P][6],
- * dL_dsh[P][M][3], dL_dscales[P][3], dL_drotations[P][4]. */
+ * dL_dsh[P][M][3], dL_dscales[P][3], dL_drotations[P][4].
+ * A reduction from the reference: R (num_rendered) must be below 2^28 - 1 = 268,435,455 instances -- the blend backward keeps a
+ * gradient-row index in 28 bits beside a 4-bit quadrant mask -- or the call returns -1 (the reference's 32-bit offsets allow 2^31;
+ * BASELINE.json's largest configuration has 1.5e7).  The forward accepts any R below 2^32. */
 int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
