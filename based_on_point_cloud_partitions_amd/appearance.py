@@ -161,15 +161,121 @@ def _plain_conv(conv):
     return isinstance(conv, torch.nn.Conv2d) and conv.bias is not None and conv.padding_mode == "zeros" and conv.weight.dtype == torch.float32
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for work that may run beside the main stream (the head's weight gradients)."""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+class _Head(torch.autograd.Function):
+    """conv1 + up1..up3 of the reference's AppearanceNetwork (appearance_network.py:48-51) as ONE autograd node around torch's own
+    convolutions, so that the backward can be ordered for the training step: the DATA-gradient chain
+    (up3 -> up2 -> up1 -> conv1 -> the network's input, which carries dL/dimage on to the rasterizer backward) runs on the caller's
+    stream, the four WEIGHT gradients -- nothing downstream needs them before the optimizer step -- are enqueued on a side stream
+    and run beside the rasterizer backward (its blend kernel is bound by VALU issue in 8160 workgroups; MIOpen's weight-gradient
+    kernels fit in beside it).  The side stream is joined, and the weight gradients are accumulated into `.grad`, in a callback the
+    autograd engine runs when the whole backward pass has been enqueued (`queue_callback`): after `loss.backward()` returns
+    everything is ordered on the caller's stream as usual.  Measured at 1080p (tools/r4_head_probe.py): head forward 0.136 ms,
+    backward 0.40 ms of which data chain 0.160 and weight gradients 0.188.
+    Limit: the weight gradients reach the parameters' `.grad` only (what `loss.backward()` -- train.py:118 -- uses);
+    `torch.autograd.grad(..., inputs=[a head weight])` does not see them.  GSR_APPEARANCE_OVERLAP=0 switches back to plain autograd."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = _lib.load()
+        ws, bs = params[0::2], params[1::2]
+        ins, outs = [], []
+        h = x
+        with torch.cuda.device(x.device):
+            s = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            for i, (w, b) in enumerate(zip(ws, bs)):
+                if i:
+                    h = F.pixel_shuffle(h, 2)
+                ins.append(h)
+                h = F.conv2d(h, w, None, 1, 1)
+                _lib.check(lib.gsr_bias_relu_forward(h.shape[1], h.shape[2] * h.shape[3], _p(h), _p(b.contiguous()), s), "gsr_bias_relu_forward")
+                outs.append(h)
+        ctx.save_for_backward(*ins, *outs, *ws)
+        ctx.n = len(ws)
+        ctx.param_refs = params  # the Parameters themselves: their .grad is written by the end-of-backward callback
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        ins, outs, ws = saved[:n], saved[n:2 * n], saved[2 * n:]
+        lib = _lib.load()
+        dev = g.device
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        cb = torch.ops.aten.convolution_backward
+        dbs, dws = [None] * n, [None] * n
+        g = g.contiguous()
+        with torch.cuda.device(dev):
+            s = ctypes.c_void_p(main.cuda_stream)
+            for i in reversed(range(n)):
+                y = outs[i]
+                C, npx = y.shape[1], y.shape[2] * y.shape[3]
+                dz = torch.empty_like(y)
+                db = torch.empty(C, dtype=torch.float32, device=dev)
+                scratch = torch.empty(lib.gsr_bias_relu_scratch_bytes(C), dtype=torch.uint8, device=dev)
+                _lib.check(lib.gsr_bias_relu_backward(C, npx, _p(g), _p(y), _p(dz), _p(db), _p(scratch), scratch.numel(), s),
+                           "gsr_bias_relu_backward")
+                dbs[i] = db
+                ready = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    dws[i] = cb(dz, ins[i], ws[i], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+                dz.record_stream(side)
+                if i > 0 or ctx.needs_input_grad[0]:
+                    gin = cb(dz, ins[i], ws[i], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+                    g = F.pixel_unshuffle(gin, 2).contiguous() if i > 0 else gin
+                else:
+                    g = None
+        weights = ctx.param_refs[0::2]
+
+        def join():
+            main.wait_stream(side)
+            with torch.no_grad():
+                for w, dw in zip(weights, dws):
+                    dw.record_stream(main)
+                    if w.grad is None:
+                        w.grad = dw
+                    else:
+                        w.grad.add_(dw)
+
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        grads = [g]
+        for i in range(n):
+            grads += [None, dbs[i]]
+        return tuple(grads)
+
+
 def _head(net, x):
     """conv1 + up1..up3 (appearance_network.py:48-51).  When the layers are the reference's (Conv2d -> ReLU, PixelShuffle -> Conv2d ->
-    ReLU) the convolutions stay torch's and bias + ReLU are fused around them; any other module is simply called."""
+    ReLU) the convolutions stay torch's, bias + ReLU are fused around them and the backward's weight gradients run on a side stream
+    (_Head); any other module is simply called."""
     ups = (net.up1, net.up2, net.up3)
     standard = _plain_conv(net.conv1) and isinstance(net.relu, torch.nn.ReLU) and x.is_cuda and all(
         isinstance(getattr(u, "pixel_shuffle", None), torch.nn.PixelShuffle) and _plain_conv(getattr(u, "conv", None)) and
         isinstance(getattr(u, "relu", None), torch.nn.ReLU) and len(list(u.children())) == 3 for u in ups)
     if not standard:
         return net.up3(net.up2(net.up1(net.relu(net.conv1(x)))))
+    convs = (net.conv1, net.up1.conv, net.up2.conv, net.up3.conv)
+    overlap = _lib.get_variant("APPEARANCE_OVERLAP", 1) and all(
+        tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (1, 1) and tuple(c.dilation) == (1, 1) and
+        c.groups == 1 for c in convs) and all(getattr(u.pixel_shuffle, "upscale_factor", None) == 2 for u in ups) and \
+        torch.is_grad_enabled() and all(c.weight.requires_grad and c.weight.is_leaf for c in convs)
+    if overlap:
+        params = []
+        for c in convs:
+            params += [c.weight, c.bias]
+        return _Head.apply(x.contiguous(), *params)
     h = _conv_bias_relu(net.conv1, x)
     for u in ups:
         h = _conv_bias_relu(u.conv, u.pixel_shuffle(h))

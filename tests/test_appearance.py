@@ -193,10 +193,16 @@ def _model(seed):
 
 
 @pytest.mark.gpu
-def test_decouple_appearance_matches_the_stock_torch_dataflow():
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_decouple_appearance_matches_the_stock_torch_dataflow(overlap):
     """The whole function (head as the module's own layers + HIP tail) against appearance_network.py:7-17 with every layer a torch
-    op, on the GPU: outputs, and the gradients of the image (both paths), the embedding and every network parameter."""
+    op, on the GPU: outputs, and the gradients of the image (both paths), the embedding and every network parameter.  overlap = 1: the
+    head is one autograd node whose weight gradients run on a side stream and reach `.grad` through the end-of-backward callback
+    (appearance._Head); a second backward must ACCUMULATE into the same `.grad` like autograd does."""
+    from based_on_point_cloud_partitions_amd import _lib
     from based_on_point_cloud_partitions_amd.appearance import decouple_appearance
+
+    _lib.set_variant("APPEARANCE_OVERLAP", overlap)
 
     from based_on_point_cloud_partitions_amd.synthetic import decouple_appearance_torch
 
@@ -215,6 +221,13 @@ def test_decouple_appearance_matches_the_stock_torch_dataflow():
     assert close(ia.grad, ib.grad) and close(a._appearance_embeddings.grad, b._appearance_embeddings.grad)
     for (n, pa), (_, pb) in zip(a.appearance_network.named_parameters(), b.appearance_network.named_parameters()):
         assert close(pa.grad, pb.grad), n
+    first = {n: p.grad.clone() for n, p in a.appearance_network.named_parameters()}
+    ta2, _ = decouple_appearance(img.clone().requires_grad_(True), a, 3)
+    (ta2 * r).sum().backward()
+    torch.cuda.synchronize()
+    for n, p in a.appearance_network.named_parameters():
+        assert (p.grad - 2 * first[n]).abs().max().item() <= 1e-5 * max(first[n].abs().max().item(), 1e-6), n
+    _lib.set_variant("APPEARANCE_OVERLAP", 1)
 
 
 @pytest.mark.gpu
