@@ -797,7 +797,8 @@ def main():
                       "seam_psnr_db": (round(ev["psnr"], 3) if np.isfinite(ev["psnr"]) else None), "seam_ssim": round(ev["ssim"], 6),
                       "note": "config 5, once after the timed region: crop -> all_gather_into_tensor of padded [maxN,59] blocks -> "
                               "first-occurrence lexicographic dedup; each rank scores its partition's camera 0 rendered from the merged "
-                              "scene against its own un-cropped partition (PSNR None = identical images)"},
+                              "scene against its own un-cropped partition (PSNR None = identical images; at N > 1 the neighbour "
+                              "partition is visible from that camera, so the seam figures mostly measure that, not the merge)"},
             "rendered_mpix_per_s_fwd": round(world * N / 1e6 / (fwd_ms * 1e-3), 1) if fwd_ms > 0 else None,
             "roofline": roofline,
             "roofline_step": {"bound": "hbm", "algorithmic_bytes": int(step_bytes),
