@@ -658,6 +658,15 @@ def main():
         gts[rank] = evaluate.render_rows(raw_block, views[rank], bg).clamp(0.0, 1.0)
         ev = evaluate.seamless_merge_and_evaluate(raw_block, rank, boxes if world > 1 else [(None, None, None, None)], views, gts, bg)
     merged_rows = int(ev["merged"].shape[0])
+    # the dedup again, three times, on this rank's own rows: ev["dedup_ms"] above is ONE call right behind the process group's first
+    # collectives (at N = 1 right behind RCCL's init: host-side noise several times the algorithm's own time)
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        for _ in range(3):
+            merge.dedup_first_lexicographic(raw_block)
+        torch.cuda.synchronize()
+        dedup_steady_ms = 1e3 * (time.perf_counter() - td) / 3
     del raw_block, gts
 
     full = None
@@ -793,7 +802,8 @@ def main():
             "merge": {"world_size": ev["world_size"], "rows_per_rank_after_crop": ev["counts"], "merged_rows": merged_rows,
                       "merge_allgather_ms": round(ev["merge_allgather_ms"], 3),
                       "allgather_bytes_per_rank": int(max(ev["counts"]) * merge.ROW * 4),
-                      "dedup_ms": round(ev["dedup_ms"], 3), "views_scored": ev["views_scored"],
+                      "dedup_ms": round(ev["dedup_ms"], 3), "dedup_ms_own_rows_steady": round(dedup_steady_ms, 3),
+                      "views_scored": ev["views_scored"],
                       "seam_psnr_db": (round(ev["psnr"], 3) if np.isfinite(ev["psnr"]) else None), "seam_ssim": round(ev["ssim"], 6),
                       "note": "config 5, once after the timed region: crop -> all_gather_into_tensor of padded [maxN,59] blocks -> "
                               "first-occurrence lexicographic dedup; each rank scores its partition's camera 0 rendered from the merged "
