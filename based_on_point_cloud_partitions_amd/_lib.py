@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GSR_LIBRARY selects another build of the same library (tools/build_ab.sh: A/B variants live in their own directory, the
+# GSR_LIBRARY selects another build of the same library (tools/ab_build.sh + tools/ab_run.sh: A/B variants live in their own directory, the
 # shipped .so is never rebuilt in place); gsr_build_info() says what a loaded binary was built with.
 SO_PATH = os.environ.get("GSR_LIBRARY") or os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
 ABI_VERSION = 15

@@ -138,8 +138,18 @@ __device__ __forceinline__ void reduce_rows_balanced(const float4* __restrict__ 
 // it takes 1.5x as long).  Culled Gaussians read no SH at all.
 // BAL: the cost-balanced work split and the lane-per-row summation (the default); !BAL: BS consecutive Gaussians per workgroup, every
 // thread adds its own Gaussian's rows (GSR_GB_BALANCED=0, and scenes without any instance).
+#ifndef GSR_GB_WPE_MAX
+#define GSR_GB_WPE_MAX 8
+#endif
+#ifndef GSR_GB_WPE
+#define GSR_GB_WPE 0  // experiment: waves per SIMD the register allocation aims at (0: the compiler's choice, 4 at 120 VGPRs)
+#endif
 template <bool RAW, int BS, bool DIRECT, int RK, bool BAL>
-__global__ void __launch_bounds__(BS) gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
+__global__ void __launch_bounds__(BS)
+#if GSR_GB_WPE
+__attribute__((amdgpu_waves_per_eu(GSR_GB_WPE, GSR_GB_WPE_MAX)))
+#endif
+gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
 {
     extern __shared__ float s_tile[];  // [BS][3M + 1]
     // this workgroup's Gaussians: the cost-balanced split stored by the forward (gsr_part_*, common.h), or BS consecutive ones

@@ -70,8 +70,18 @@ struct PreprocessPtrs {
 // RAW: scales / rotations / opacities are the pre-activation parameters (exp / normalize / sigmoid applied here) and the
 // SH rows are assembled in LDS from features_dc + features_rest -- the four activation passes and the 96 MB torch.cat of
 // scene/gaussian_model.py:102-122 never touch HBM.
+#ifndef GSR_PRE_WPE_MAX
+#define GSR_PRE_WPE_MAX 8
+#endif
+#ifndef GSR_PRE_WPE
+#define GSR_PRE_WPE 0  // experiment (with GSR_PRE_WPE_MAX): waves per SIMD the register allocation aims at (0: the compiler's choice, 5 at 91 VGPRs)
+#endif
 template <bool RAW>
-__global__ void __launch_bounds__(256) preprocess_kernel(PreprocessPtrs a, float focal_x, float focal_y, int gx, int gy)
+__global__ void __launch_bounds__(256)
+#if GSR_PRE_WPE
+__attribute__((amdgpu_waves_per_eu(GSR_PRE_WPE, GSR_PRE_WPE_MAX)))
+#endif
+preprocess_kernel(PreprocessPtrs a, float focal_x, float focal_y, int gx, int gy)
 {
     // SH rows are 192 B per Gaussian: the workgroup's 256 rows come in through LDS with coalesced 16-byte loads and are read
     // per thread with an odd row stride (see gaussian_backward.hip)

@@ -109,7 +109,7 @@ def test_no_cpu_fallback():
 
 def test_shipped_library_has_no_ablation_or_extra_flags():
     """GSR_ABLATE / GSR_BIN_ABLATE (timing experiments that give wrong results on purpose) are 0 in the built .so and it was built
-    without make EXTRA=... (tools/build_ab.sh builds such variants elsewhere)."""
+    without make EXTRA=... (tools/ab_build.sh + tools/ab_run.sh builds such variants elsewhere)."""
     from based_on_point_cloud_partitions_amd import _lib
 
     assert not os.environ.get("GSR_LIBRARY")
