@@ -68,11 +68,20 @@ static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 // (emit_partition_kernel / emit_keys_kernel) store every workgroup's first Gaussian in GeomLayout::wg_first, so the split costs the
 // backward one load per workgroup and its duration no longer depends on the order of the Gaussians in memory (a spatially sorted
 // model puts all the many-row Gaussians of a close-up region into the same workgroups).
-__host__ __device__ static inline uint32_t gsr_part_cap(int P) { return 2u * (((uint32_t)(P > 0 ? P : 1) + 127u) / 128u) + 8u; }
+#ifndef GSR_PART_W
+#define GSR_PART_W 8        // cost of a Gaussian in gradient rows (experiment switch; see profiles/README.md)
+#endif
+#ifndef GSR_PART_SHIFT
+#define GSR_PART_SHIFT 10   // log2 of the cost a workgroup takes
+#endif
+__host__ __device__ static inline uint32_t gsr_part_cap(int P)
+{
+    return (2u * (((uint32_t)(P > 0 ? P : 1) + 127u) / 128u) + 8u) << (GSR_PART_SHIFT < 10 ? 10 - GSR_PART_SHIFT : 0);
+}
 __host__ __device__ static inline int gsr_part_shift(int P, uint32_t total_rows)
 {
-    const unsigned long long f = 8ull * (unsigned long long)(P > 0 ? P : 0) + total_rows;
-    int sh = 10;
+    const unsigned long long f = (unsigned long long)GSR_PART_W * (unsigned long long)(P > 0 ? P : 0) + total_rows;
+    int sh = GSR_PART_SHIFT;
     while ((f >> sh) + 1ull > (unsigned long long)gsr_part_cap(P)) sh++;
     return sh;
 }
@@ -452,8 +461,8 @@ __device__ __forceinline__ void gsr_part_store(uint32_t* __restrict__ wg_first, 
                                                uint32_t total_rows)
 {
     const int sh = gsr_part_shift(P, total_rows);
-    const uint32_t w0 = (uint32_t)((8ull * (unsigned long long)idx + rows_excl) >> sh);
-    const uint32_t w1 = (uint32_t)((8ull * (unsigned long long)(idx + 1) + rows_incl) >> sh);
+    const uint32_t w0 = (uint32_t)(((unsigned long long)GSR_PART_W * (unsigned long long)idx + rows_excl) >> sh);
+    const uint32_t w1 = (uint32_t)(((unsigned long long)GSR_PART_W * (unsigned long long)(idx + 1) + rows_incl) >> sh);
     for (uint32_t w = w0 + 1; w <= w1; w++) wg_first[w] = (uint32_t)(idx + 1);
     if (idx == 0) wg_first[0] = 0u;
 }

@@ -156,7 +156,7 @@ gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
     int w_first, w_last;
     if (BAL) {
         const uint32_t total = a.row_total[0];
-        const uint32_t nw = (uint32_t)((8ull * (unsigned long long)a.P + total) >> gsr_part_shift(a.P, total)) + 1u;
+        const uint32_t nw = (uint32_t)(((unsigned long long)GSR_PART_W * (unsigned long long)a.P + total) >> gsr_part_shift(a.P, total)) + 1u;
         if (blockIdx.x >= nw) return;
         w_first = (int)a.wg_first[blockIdx.x];
         w_last = blockIdx.x + 1 < nw ? (int)a.wg_first[blockIdx.x + 1] : a.P;
@@ -635,7 +635,8 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     lds += (size_t)gsr_variant("LDS_PAD", 0);
     // balanced split: gsr_part_cap(P) workgroups cover every scene (the ones beyond the split's end leave at once); a second grid
     // dimension only when the split's workgroups may hold more than `bs` Gaussians (rows <= instances: an upper bound of the shift)
-    const uint32_t cols = a.wg_first ? (uint32_t)(((128u << (gsr_part_shift(a.P, a.rows_bound) - 10)) + bs - 1) / bs) : 1u;
+    // (a workgroup of the split holds at most 2^shift / GSR_PART_W Gaussians)
+    const uint32_t cols = a.wg_first ? (uint32_t)((((1u << gsr_part_shift(a.P, a.rows_bound)) / GSR_PART_W) + bs - 1) / bs) : 1u;
     const dim3 grid(a.wg_first ? gsr_part_cap(a.P) : (uint32_t)((a.P + bs - 1) / bs), cols), block(bs);
 #define GB_LAUNCH(RAW_, BS_, DIRECT_, RK_)                                                                                      \
     do {                                                                                                                        \

@@ -150,6 +150,18 @@ def test_lists_beyond_2048_entries_without_the_mid_kernel():
     _fwd_bwd(P=3000, W=160, H=128, focal=100.0, seed=1, scale_lo=0.01, scale_hi=0.15)
 
 
+def test_giant_splats_many_gradient_rows_per_gaussian():
+    """Far more than 8 gradient rows per Gaussian: the per-Gaussian backward's cost-balanced split (common.h, gsr_part_*) then needs more
+    than its 2 * ceil(P / 128) + 8 workgroups, raises its shift and shares a workgroup's Gaussians over a second grid dimension; rectangles
+    beyond 64 tiles own a row per tile (no reach mask), so single Gaussians own hundreds of rows and the lane-per-row scan carries a
+    segment over many 64-row steps."""
+    st, ctx = _fwd_bwd(P=300, W=256, H=256, focal=160.0, seed=41, scale_lo=0.8, scale_hi=2.0, bg=(0.1, 0.1, 0.1))
+    vis = st["radii"] > 0
+    assert st["num_rendered"] > 100 * vis.sum()  # > 100 instances per visible Gaussian
+    st, ctx = _fwd_bwd(P=5000, W=256, H=256, focal=160.0, seed=42, scale_lo=0.15, scale_hi=0.5)
+    assert st["num_rendered"] > 12 * (st["radii"] > 0).sum()
+
+
 def test_many_equal_depths_tie_break_by_index():
     # exact duplicates of positions -> identical depth bits: ties must come out in ascending Gaussian index (the stable
     # sort's emission order); also drives the per-tile bucket sort into its overflow (bitonic) path

@@ -199,3 +199,34 @@ def test_bench_launcher_starts_the_ranks_as_a_child_process(monkeypatch):
     monkeypatch.setenv("RANK", "0")
     bench.launch_ranks_if_needed(["--gpus=4"])
     assert not seen
+
+
+def test_dedup_matches_numpy_unique_on_adversarial_coordinates():
+    """np.unique(points, axis=0, return_index=True) (scene/ptgs/merge_partitions.py:152-158) against merge.dedup_first_lexicographic on
+    coordinates chosen to break an integer-key sort: +-0.0 (equal under float comparison), denormals, +-inf, huge / tiny magnitudes,
+    many exact duplicates in every prefix of (x, y, z), and rows that differ in z only (the least significant key)."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    special = [0.0, -0.0, 1.0, -1.0, 1e-45, -1e-45, 1.17549435e-38, 3.4e38, -3.4e38, float("inf"), float("-inf"), 0.5, 2.0 ** -126, 1.0000001]
+    coord = st.one_of(st.sampled_from(special), st.floats(width=32, allow_nan=False, allow_infinity=True),
+                      st.integers(-3, 3).map(float))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.tuples(coord, coord, coord), min_size=0, max_size=60), st.integers(0, 2 ** 31 - 1))
+    def check(points, seed):
+        n = len(points)
+        rows = np.random.default_rng(seed).standard_normal((n, merge.ROW)).astype(np.float32)
+        if n:
+            rows[:, :3] = np.asarray(points, np.float32).reshape(n, 3)
+        got = merge.dedup_first_lexicographic(torch.from_numpy(rows.copy())).numpy()
+        if n == 0:
+            assert got.shape == (0, merge.ROW)
+            return
+        _, idx = np.unique(rows[:, :3], axis=0, return_index=True)
+        want = rows[idx]
+        assert got.shape == want.shape
+        assert np.array_equal(got[:, 3:], want[:, 3:])           # the same rows survive, in the same order
+        assert np.array_equal(got[:, :3], want[:, :3])           # (+0.0 == -0.0 here, as for np.unique)
+
+    check()

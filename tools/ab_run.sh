@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs the variants built by tools/ab_build.sh on the GPU box, selected through GSR_LIBRARY (based_on_point_cloud_partitions_amd/_lib.py).
-# usage: tools/ab_run.sh <tag> <config> bench|kstat [repeats]
+# usage: tools/ab_run.sh <tag> <config> bench|kstat [repeats] ["extra bench.py arguments"]
 #   bench: bench.py per variant (value / ms_per_step / slowest stages);  kstat: rocprofv3 --kernel-trace --stats per variant
-tag=$1; cfg=$2; mode=$3; rep=${4:-1}
+tag=$1; cfg=$2; mode=$3; rep=${4:-1}; extra=${5:-}
 root=$PWD; out=$root/gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 for r in $(seq 1 $rep); do
 for d in $root/tools/scratch/ab_${tag}_*; do
@@ -19,11 +19,11 @@ print("[$flags]", {k: round(v,1) for k,v in r.items() if any(s in k for s in ("t
 PY
     find $out -name "k${n}_kernel_trace.csv" -delete
   else
-    timeout -k 10 300 python3 bench.py --config $cfg --steps 256 --warmup 8 --no-cpu-baseline --dist off > $out/b_${n}_$r.log 2> $out/b_${n}_$r.err
+    timeout -k 10 300 python3 bench.py --config $cfg --steps 256 --warmup 8 --no-cpu-baseline --dist off $extra > $out/b_${n}_$r.log 2> $out/b_${n}_$r.err
     python3 - <<PY
 import json
 d=json.loads([l for l in open("$out/b_${n}_$r.log") if l.startswith("{")][-1])
-print("[$flags]", d["build_info"].split("extra=")[1], d["ms_per_step"], {k["kernel"]: k["avg_ms"] for k in d["roofline_kernels"]})
+print("[$flags] $extra", d["ms_per_step"], {k["kernel"]: k["avg_ms"] for k in d["roofline_kernels"]})
 PY
   fi
   unset GSR_LIBRARY
