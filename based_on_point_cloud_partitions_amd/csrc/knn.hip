@@ -249,6 +249,98 @@ __global__ void __launch_bounds__(256) knn_kernel(int P, uint32_t num_boxes, int
     }
 }
 
+// Wave-autonomous variant (round 4, the default): a wave is one 64-point box of Morton-sorted queries and never waits for the other
+// waves of its workgroup.  (1) Its own box first: the 64 points go to the wave's LDS slice and every lane scans them -- an exact 3-NN
+// inside the box, i.e. a much tighter reject radius than the +-3 Morton neighbours of the reference (simple_knn.cu:156-163).  (2) The
+// groups of boxes are visited outward from the wave's own group (own, +1, -1, +2, ...: Morton neighbours are spatial neighbours more often
+// than not, so the radius shrinks early); a group, then a box, is entered when ANY lane cannot reject its AABB -- a ballot, no barrier --
+// and a box that is entered is loaded once (lane k loads point k, coalesced), parked in the wave's LDS slice and scanned with broadcast
+// reads by the lanes that want it.  Exactness: a box is skipped for a lane only when its AABB is farther than the lane's current third-best
+// distance, so the result is the exact 3-NN set whatever the order.  500k points: 796 -> ~250 candidate distances per point, no
+// __syncthreads in the kernel (the workgroup-cooperative kernel above spends its time in 245 + ~400 workgroup votes per workgroup).
+__global__ void __launch_bounds__(256) knn_wave_kernel(int P, uint32_t num_boxes, int group, const float4* __restrict__ sorted,
+                                                       const float* __restrict__ boxes, const float* __restrict__ supers,
+                                                       float* __restrict__ out, unsigned long long* __restrict__ evals)
+{
+    __shared__ float s_pts[4][3][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t my_box = blockIdx.x * 4u + (uint32_t)wave;  // wave-uniform
+    if (my_box >= num_boxes) return;
+    float* sx = s_pts[wave][0];
+    float* sy = s_pts[wave][1];
+    float* sz = s_pts[wave][2];
+    const int idx = (int)my_box * 64 + lane;
+    const bool valid = idx < P;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    uint32_t orig = 0, my_evals = 0;
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    // loads box `b` (lane k: point k) into the wave's LDS slice; returns the number of points in it
+    auto stage = [&](uint32_t b) -> int {
+        const int base = (int)b * 64;
+        const int cnt = min(64, P - base);
+        if (lane < cnt) {
+            const float4 c = sorted[base + lane];
+            sx[lane] = c.x; sy[lane] = c.y; sz[lane] = c.z;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return cnt;
+    };
+    auto release = [&]() {  // every lane is done reading the slice before the next box overwrites it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (valid) {
+        const float4 q = sorted[idx];
+        qx = q.x; qy = q.y; qz = q.z; orig = __float_as_uint(q.w);
+    }
+    {   // (1) the wave's own box
+        const int cnt = stage(my_box);
+        if (valid) {
+            my_evals += (uint32_t)cnt;
+            for (int k = 0; k < cnt; k++) {
+                if (k == lane) continue;
+                update3(qx, qy, qz, sx[k], sy[k], sz[k], b0, b1, b2);
+            }
+        }
+        release();
+    }
+    // (2) the other boxes, group by group, outward from the own group
+    const uint32_t num_supers = (num_boxes + (uint32_t)group - 1) / (uint32_t)group;
+    const uint32_t own_super = my_box / (uint32_t)group;
+    for (uint32_t step = 0; step < 2 * num_supers; step++) {
+        // step 0: own; 1: own + 1; 2: own - 1; 3: own + 2; ...  (indices outside [0, num_supers) are skipped)
+        const long long sb_ = (long long)own_super + ((step & 1u) ? (long long)((step + 1) >> 1) : -(long long)(step >> 1));
+        if (sb_ < 0 || sb_ >= (long long)num_supers) continue;
+        const uint32_t sb = (uint32_t)sb_;
+        const float sdist = dist_box_point(supers + sb * 6, qx, qy, qz);
+        if (__builtin_amdgcn_ballot_w64(valid && !(sdist > b2)) == 0ull) continue;
+        const uint32_t bend = min(num_boxes, (sb + 1) * (uint32_t)group);
+        for (uint32_t b = sb * (uint32_t)group; b < bend; b++) {
+            if (b == my_box) continue;
+            const float dist = dist_box_point(boxes + b * 6, qx, qy, qz);
+            const bool want = valid && !(dist > b2);
+            if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
+            const int cnt = stage(b);
+            if (want) {
+                my_evals += (uint32_t)cnt;
+                for (int k = 0; k < cnt; k++) update3(qx, qy, qz, sx[k], sy[k], sz[k], b0, b1, b2);
+            }
+            release();
+        }
+    }
+    if (valid) out[orig] = (b0 + b1 + b2) / 3.0f;
+    if (evals) {
+        unsigned long long e = my_evals;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off, 64);
+        if (lane == 0) atomicAdd(evals, e);
+    }
+}
+
 }  // namespace
 
 size_t gsr_knn_scratch_layout_bytes(int P) { return knn_layout(P).bytes; }
@@ -287,6 +379,13 @@ int gsr_knn_run(int P, const float* points, float* out, void* scratch, size_t sc
     }
     const int group = max(1, gsr_variant("KNN_GROUP", 32));
     float* supers = (float*)(base + L.supers);
+    if (gsr_variant("KNN_WAVE", 1)) {  // wave-autonomous kernel: 64-point boxes, no workgroup barriers
+        const uint32_t nb = (uint32_t)((P + 63) / 64);
+        hipLaunchKernelGGL(box_minmax_kernel<64>, dim3(nb), dim3(256), 0, s, P, sorted, boxes);
+        hipLaunchKernelGGL(super_minmax_kernel, dim3((nb / group + 256) / 256), dim3(256), 0, s, nb, group, boxes, supers);
+        hipLaunchKernelGGL(knn_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, s, P, nb, group, sorted, boxes, supers, out, evals);
+        return 0;
+    }
     switch (gsr_variant("KNN_BOX", 64)) {
         case 1024: GSR_KNN_LAUNCH(1024); break;
         case 512: GSR_KNN_LAUNCH(512); break;

@@ -784,16 +784,17 @@ def main():
             "ms_per_step_reference_lists": round(ref_lists_ms, 4) if ref_lists_ms is not None else None,
             "knn_init_ms": knn_ms,
             "knn_points_per_s": round(P / (knn_ms * 1e-3), 1),
-            # the kNN is not bandwidth-bound (its ~120 B per point are read once; the candidate points come out of LDS): what bounds it
-            # is the number of candidate distances a query evaluates -- 8 flops + a 3-deep compare-and-swap each, from the box the query
-            # cannot reject -- so the figure is candidate evaluations per second against the fp32 vector peak, the HBM figure beside it
+            # the kNN is not bandwidth-bound (its ~120 B per point are read once; the candidate points come out of LDS): its work is the
+            # candidate distances a query evaluates -- 8 flops + a 3-deep compare-and-swap each, from the boxes the query cannot reject --
+            # so the figure is candidate evaluations per second against the fp32 vector peak, the HBM figure beside it
             "roofline_knn": {"bound": "valu", "candidate_evals": knn_evals, "candidate_evals_per_point": round(knn_evals / max(P, 1), 1),
                              "flops_per_eval": 8, "achieved": round(8 * knn_evals / (knn_ms * 1e-3) / 1e12, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(8 * knn_evals / (knn_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
                              "hbm": {"algorithmic_bytes": 120 * P, "achieved": round(120 * P / 1e9 / (knn_ms * 1e-3), 1), "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": round(120 * P / 1e9 / (knn_ms * 1e-3) / HBM_PEAK_GBS, 4)},
-                             "note": "whole distCUDA2 call (8 launches incl. the Morton sort); exact 3-NN: 64-point boxes in groups of 32, "
-                                     "a box no query of the workgroup can reject is scanned from LDS"},
+                             "note": "whole distCUDA2 call (min/max, Morton codes, radix sort, gather, box AABBs, search); exact 3-NN: a wave is one "
+                                     "64-point box of Morton-sorted queries, scans its own box first, then walks the box groups outward and "
+                                     "scans from LDS every box one of its lanes cannot reject (no workgroup barrier)"},
             "rccl_world_size": len(dist_state["ranks_seen"]), "rccl_ranks_seen": dist_state["ranks_seen"],
             "collective_backend": (dist.get_backend() if dist is not None else None), "collective_init_error": dist_state["error"],
             "collective_init": ("before the warm-up (N > 1: the timed region is bracketed by its barriers)" if world > 1 else

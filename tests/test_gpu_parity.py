@@ -546,17 +546,28 @@ def test_radix_sort_is_stable_and_correct(n, end_bit):
     assert np.array_equal(vo, vals[order])
 
 
-@pytest.mark.parametrize("P", [1, 2, 3, 4, 7, 1023, 1024, 1025, 5000, 100_000])
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 7, 63, 64, 65, 129, 1023, 1024, 1025, 5000, 100_000])
 def test_knn_bit_exact(P):
-    from based_on_point_cloud_partitions_amd import distCUDA2
+    """Both kernels: the wave-autonomous one (default) and the workgroup-cooperative one of rounds 1-3 (GSR_KNN_WAVE=0); uniform points
+    and a clustered cloud (three tight blobs + a few far outliers: boxes of very different extent, long outward walks)."""
+    from based_on_point_cloud_partitions_amd import _lib, distCUDA2
 
-    pts = np.random.default_rng(P).uniform(-4, 4, (P, 3)).astype(np.float32)
+    rng = np.random.default_rng(P)
+    pts = rng.uniform(-4, 4, (P, 3)).astype(np.float32)
     if P >= 5000:
         pts[17] = pts[4000]  # exact duplicates
         pts[18] = pts[4000]
-    want = oracle.knn_mean_dist2(pts)
-    got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    blobs = (rng.standard_normal((P, 3)) * 0.01 + rng.integers(0, 3, (P, 1)) * 5.0).astype(np.float32)
+    blobs[:: 97] = rng.uniform(-100, 100, (len(blobs[:: 97]), 3)).astype(np.float32)
+    try:
+        for wave in (1, 0):
+            _lib.set_variant("KNN_WAVE", wave)
+            for cloud in (pts, blobs):
+                want = oracle.knn_mean_dist2(cloud)
+                got = distCUDA2(torch.from_numpy(cloud).cuda()).cpu().numpy()
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (wave, P)
+    finally:
+        _lib.set_variant("KNN_WAVE", 1)
 
 
 def test_knn_config2_points_and_fixture():
