@@ -399,10 +399,19 @@ __global__ void __launch_bounds__(256) tile_colscan_banded_kernel(BandGeom G, ui
     if (blockIdx.x * 32 >= tn) return;
     constexpr int per = BAND_SLICES / 8;
     uint32_t* col = table + (size_t)b * BAND_SLICES * G.tmax + t;
+    // Order of the slices' runs inside a tile segment.  A run is ~4 entries (35 bytes), so nearly every 64-byte piece of a segment is shared
+    // by the runs of two or three slices.  GSR_COLSCAN_XCD (default): group sg takes the slices sg, sg + 8, sg + 16, ... -- the workgroups
+    // of the scatter that run on ONE XCD (workgroup index mod 8; a band's first workgroup is a multiple of 64) -- so the slices that share
+    // a piece write it through the same L2, which merges their partial writes; with consecutive slices per group (round 1-3) neighbours
+    // sat on different XCDs and each L2 wrote its part of the piece back on its own (62 MiB written for 18 MB of pairs).
+#ifndef GSR_COLSCAN_XCD
+#define GSR_COLSCAN_XCD 1
+#endif
+    auto slice_of = [&](int k) { return GSR_COLSCAN_XCD ? sg + 8 * k : sg * per + k; };
     uint32_t sum = 0;
     if (t < tn) {
 #pragma unroll
-        for (int k = 0; k < per; k++) sum += col[(size_t)(sg * per + k) * G.tmax];
+        for (int k = 0; k < per; k++) sum += col[(size_t)slice_of(k) * G.tmax];
     }
     part[sg][tl] = sum;
     __syncthreads();
@@ -411,7 +420,7 @@ __global__ void __launch_bounds__(256) tile_colscan_banded_kernel(BandGeom G, ui
     if (t < tn) {
 #pragma unroll
         for (int k = 0; k < per; k++) {
-            uint32_t* e = col + (size_t)(sg * per + k) * G.tmax;
+            uint32_t* e = col + (size_t)slice_of(k) * G.tmax;
             const uint32_t c = *e;
             *e = run;
             run += c;
