@@ -229,7 +229,7 @@ const char* gsr_last_error(void) { return g_err; }
 size_t gsr_geometry_bytes(int P) { return gsr_geom_layout(P).bytes; }
 size_t gsr_image_bytes(int W, int H) { return gsr_image_layout(W, H).bytes; }
 size_t gsr_binning_bytes(int64_t R, int P, int W, int H) { return gsr_bin_layout((long)R, P, W, H).bytes; }
-// Backward scratch: one 48-byte gradient row per (Gaussian, tile) instance at most (only reachable instances own one).
+// Backward scratch: one gradient row (GSR_GROW_F = 9 floats) per (Gaussian, tile) instance at most (only reachable instances own one).
 size_t gsr_backward_scratch_bytes(int64_t R, int W, int H)
 {
     (void)W; (void)H;

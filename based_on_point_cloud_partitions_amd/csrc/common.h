@@ -9,7 +9,10 @@
 #define GSR_TILE_Y 16
 #define GSR_TILE_PIX 256
 #define GSR_SPLAT_F 16   // floats per packed per-Gaussian record (64 B, 64-byte aligned: a gather never straddles a line)
-#define GSR_GROW_F 12    // floats per per-instance gradient row (48 B)
+#ifndef GSR_GROW_F
+#define GSR_GROW_F 9     // floats per per-instance gradient row: the nine sums, 36 B (12 = the 48-byte rows of rounds 1-3, three aligned float4)
+#endif
+#define GSR_SUMS_F 12    // row stride of the gsr_debug_capture_sums test hook
 
 // Packed per-Gaussian record written by the preprocess kernel and gathered by the blend kernels.
 // One 64-byte row (16 B quarters) instead of the reference's four separate arrays
@@ -57,6 +60,40 @@ struct BinLayout {
 // loads of 2-4 dwords need no more than that)
 typedef float gsr_f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float gsr_f3u __attribute__((ext_vector_type(3), aligned(4)));
+
+// One gradient row in HBM: nine floats.  36-byte rows (GSR_GROW_F = 9): two dword-aligned 16-byte accesses + one dword; 48-byte rows (12):
+// three aligned float4 with three padding floats.
+__device__ __forceinline__ void gsr_row_store(float* __restrict__ rows, size_t row, const float* v)
+{
+    float* o = rows + row * GSR_GROW_F;
+    if (GSR_GROW_F == 12) {
+        float4* o4 = reinterpret_cast<float4*>(o);
+        o4[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o4[1] = make_float4(v[4], v[5], v[6], v[7]);
+        o4[2] = make_float4(v[8], 0.f, 0.f, 0.f);
+    } else {
+        gsr_f4u a, b;
+        a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3];
+        b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
+        *reinterpret_cast<gsr_f4u*>(o) = a;
+        *reinterpret_cast<gsr_f4u*>(o + 4) = b;
+        o[8] = v[8];
+    }
+}
+__device__ __forceinline__ void gsr_row_load(const float* __restrict__ rows, size_t row, float* v)
+{
+    const float* o = rows + row * GSR_GROW_F;
+    if (GSR_GROW_F == 12) {
+        const float4* o4 = reinterpret_cast<const float4*>(o);
+        const float4 a = o4[0], b = o4[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = o[8];
+    } else {
+        const gsr_f4u a = *reinterpret_cast<const gsr_f4u*>(o), b = *reinterpret_cast<const gsr_f4u*>(o + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = o[8];
+    }
+}
 
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 

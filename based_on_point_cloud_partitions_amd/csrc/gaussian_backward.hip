@@ -56,7 +56,7 @@ __device__ __forceinline__ float dpp_read(float v)  // the DPP-selected lane's v
 // over the Gaussians: the earlier scheme (every thread adds its own Gaussian's rows) took as long as the Gaussian with most rows,
 // per chunk -- 2.2x slower on a spatially sorted model, whose workgroups hold either many-row or few-row Gaussians.
 template <int BS>
-__device__ __forceinline__ void reduce_rows_balanced(const float4* __restrict__ g4, const uint32_t* s_off, float* s_sum, int cnt)
+__device__ __forceinline__ void reduce_rows_balanced(const float* __restrict__ grad_rows, const uint32_t* s_off, float* s_sum, int cnt)
 {
     constexpr int NW = BS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,20 +79,19 @@ __device__ __forceinline__ void reduce_rows_balanced(const float4* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 9; i++) carry[i] = 0.f;
     bool cont = false;  // the segment of the previous step's last row goes on in this step
-    float4 n0, n1, n2;
+    float nx[9];
     auto request = [&](uint32_t base) {
         const uint32_t r = base + lane;
-        n0 = n1 = n2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < we) {
-            n0 = g4[(size_t)r * 3];
-            n1 = g4[(size_t)r * 3 + 1];
-            n2 = g4[(size_t)r * 3 + 2];
-        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) nx[i] = 0.f;
+        if (r < we) gsr_row_load(grad_rows, r, nx);
     };
     request(ws);
     const uint32_t l15 = lane & 15, l31 = lane & 31;
     for (uint32_t base = ws; base < we; base += 64) {
-        float v[9] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x};
+        float v[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) v[i] = nx[i];
         if (base + 64 < we) request(base + 64);
         const uint32_t r = base + lane;
         const bool valid = r < we;
@@ -207,7 +206,7 @@ gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
         }
         if (BS + threadIdx.x <= (unsigned)rows) s_off[BS] = a.row_offsets[gbase + BS - 1];  // (thread 0 when the pass is full)
         __syncthreads();
-        reduce_rows_balanced<BS>(reinterpret_cast<const float4*>(a.grad_rows), s_off, s_sum, rows);
+        reduce_rows_balanced<BS>(a.grad_rows, s_off, s_sum, rows);
         __syncthreads();
         if (valid && s_off[threadIdx.x + 1] != s_off[threadIdx.x]) {
 #pragma unroll
@@ -225,6 +224,19 @@ gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
             my_off = __float_as_uint(q3.x);
             my_n = gsr_splat_rows(__float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w), a.tiles_touched[idx]);
         }
+        if (GSR_GROW_F != 12) {  // 36-byte rows: plain dword copies of a chunk, every thread adds its own Gaussian's rows
+            const uint32_t CHg = (uint32_t)a.lds_floats / GSR_GROW_F;
+            for (uint32_t cb = begin; cb < end; cb += CHg) {
+                const uint32_t nrows = min(CHg, end - cb);
+                for (uint32_t f = threadIdx.x; f < nrows * GSR_GROW_F; f += BS) s_tile[f] = a.grad_rows[(size_t)cb * GSR_GROW_F + f];
+                __syncthreads();
+                const uint32_t lo = max(my_off, cb), hi = min(my_off + my_n, cb + nrows);
+                for (uint32_t r = lo; r < hi; r++)
+#pragma unroll
+                    for (int i = 0; i < 9; i++) g[i] += s_tile[(r - cb) * GSR_GROW_F + i];
+                __syncthreads();
+            }
+        } else {
         const uint32_t CH = DIRECT ? (uint32_t)(RK * BS) : (uint32_t)a.lds_floats / GSR_GROW_F;  // rows per chunk
         float4* s_rows = reinterpret_cast<float4*>(s_tile);
         const float4* g4 = reinterpret_cast<const float4*>(a.grad_rows);
@@ -262,6 +274,7 @@ gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
             }
             __syncthreads();
         }
+        }
     }
 
     if (RAW && !DIRECT) {
@@ -290,7 +303,7 @@ gaussian_backward_kernel(GaussBackwardPtrs a, float h_x, float h_y)
     const float dLc_x = g[GR_CX], dLc_y = g[GR_CY], dLc_w = g[GR_CW];
     float dL_dcol[3] = {g[GR_R], g[GR_G], g[GR_B]};
     if (a.sums_out) {  // test hook: exactly the sums the chain below consumes
-        float* so = a.sums_out + (size_t)idx * GSR_GROW_F;
+        float* so = a.sums_out + (size_t)idx * GSR_SUMS_F;
 #pragma unroll
         for (int i = 0; i < 9; i++) so[i] = g[i];
     }
@@ -628,9 +641,9 @@ void gsr_launch_gaussian_backward(const GaussBackwardArgs& a, hipStream_t s)
     // LDS: the SH tile and room for 4 gradient rows per Gaussian and chunk, or (DIRECT) the row chunk / the dL/dSH pieces alone
     // DIRECT: chunks of GB_RK gradient rows per thread (500k Gaussians: 1 -> 82 us, 2 or 4 -> 86 us)
     const int rk = gsr_variant("GB_RK", 1) == 2 ? 2 : 1;
-    size_t lds = direct ? (size_t)rk * bs * GSR_GROW_F * 4 : (size_t)bs * (3 * a.M + 1) * 4;
+    size_t lds = direct ? (size_t)rk * bs * 12 * 4 : (size_t)bs * (3 * a.M + 1) * 4;
     if (direct && lds < (size_t)bs * 17 * 4) lds = (size_t)bs * 17 * 4;  // the dL/dSH pieces
-    if (!direct && lds < (size_t)4 * bs * GSR_GROW_F * 4) lds = (size_t)4 * bs * GSR_GROW_F * 4;
+    if (!direct && lds < (size_t)4 * bs * 12 * 4) lds = (size_t)4 * bs * 12 * 4;
     p.lds_floats = (int)(lds / 4);
     lds += (size_t)gsr_variant("LDS_PAD", 0);
     // balanced split: gsr_part_cap(P) workgroups cover every scene (the ones beyond the split's end leave at once); a second grid

@@ -4,7 +4,7 @@
 // float atomics top out near 1.3 TB/s chip-wide and collapse when lanes scatter, so this kernel never uses them: the 9 partial sums
 // of a list entry are reduced across the 64 lanes of a wave with DPP adds (fixed tree), the waves of a tile are combined in LDS (float
 // atomics with exactly two addends per row: order-independent),
-// and every reachable (Gaussian, tile) instance writes ONE 48-byte gradient row with plain stores.  Rows are numbered per Gaussian
+// and every reachable (Gaussian, tile) instance writes ONE 36-byte gradient row (nine floats; 48-byte rows with three padding floats until round 4) with plain stores.  Rows are numbered per Gaussian
 // (first row + rank of the tile among the tiles its splat can reach, gsr_reach_mask), so the rows of one Gaussian are contiguous and
 // the per-Gaussian kernel sums them in a fixed order: gradients are bitwise reproducible run to run, unlike the reference's.
 //
@@ -235,9 +235,8 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                 row = __float_as_uint(q3.x) + tilepos;
                 keep = !gsr_tile_cannot_touch(q0.x, q0.y, q0.z, q0.w, q1.x, pthr, tile_x0, tile_y0);
                 if (!keep) {
-                    float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
-                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                    o[0] = z; o[1] = z; o[2] = z;
+                    const float z[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    gsr_row_store(grad_rows, row, z);
                 }
             }
             // an instance that owns a row but reaches no quadrant (the two tests round differently) is flushed as a zero row
@@ -384,7 +383,7 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             while (entry(opA0, opB0, opC0, opA1, opB1, opC1) && entry(opA1, opB1, opC1, opA0, opB0, opC0)) {}
         }
         __syncthreads();
-        // ---- flush: entry `tid` of the batch -> one 48-byte row ----
+        // ---- flush: entry `tid` of the batch -> one gradient row ----
         if (tid < BATCH) {
             const uint32_t frow = s_row[tid] & GSR_NO_ROW;
             if (frow != GSR_NO_ROW) {
@@ -398,10 +397,8 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
                 const float gmx = op * (-cx * r[1] - cy * r[2]) * ddelx_dx;
                 const float gmy = op * (-cz * r[2] - cy * r[1]) * ddely_dy;
                 const float hop = -0.5f * op;
-                float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)frow * GSR_GROW_F);
-                o[0] = make_float4(gmx, gmy, hop * r[3], hop * r[4]);
-                o[1] = make_float4(hop * r[5], r[0], r[6], r[7]);
-                o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+                const float out9[9] = {gmx, gmy, hop * r[3], hop * r[4], hop * r[5], r[0], r[6], r[7], r[8]};
+                gsr_row_store(grad_rows, frow, out9);
             }
         }
     }
@@ -428,9 +425,8 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
             row = __float_as_uint(q3.x) + (uint32_t)__popcll(mask & ((1ull << tilepos) - 1ull));
         } else
             row = __float_as_uint(q3.x) + tilepos;
-        float4* o = reinterpret_cast<float4*>(grad_rows + (size_t)row * GSR_GROW_F);
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        o[0] = z; o[1] = z; o[2] = z;
+        const float z[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        gsr_row_store(grad_rows, row, z);
     }
 }
 

@@ -36,7 +36,7 @@ int gsr_abi_version(void);
 const char* gsr_last_error(void);
 
 /* Sizes in bytes of the opaque state buffers (required<GeometryState/ImageState/BinningState>,
- * rasterizer_impl.h:67-73) and of the backward scratch (one 48-byte gradient row per instance). */
+ * rasterizer_impl.h:67-73) and of the backward scratch (one 36-byte gradient row -- nine floats -- per instance). */
 size_t gsr_geometry_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
 size_t gsr_binning_bytes(int64_t R, int P, int W, int H);

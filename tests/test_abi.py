@@ -36,7 +36,7 @@ def test_size_queries():
     lib = _lib.load()
     assert lib.gsr_geometry_bytes(500000) >= 500000 * (48 + 24 + 3 + 4 + 4)
     assert lib.gsr_binning_bytes(1000, 100, 64, 64) >= 1000 * 24
-    assert lib.gsr_backward_scratch_bytes(1000, 64, 64) >= 48000
+    assert lib.gsr_backward_scratch_bytes(1000, 64, 64) >= 36000  # nine floats per gradient row (one row per instance at most)
     assert lib.gsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 8
     assert lib.gsr_knn_scratch_bytes(1000) > 0 and lib.gsr_sort_scratch_bytes(1000) > 0
     # the R-dependent part of the binning buffer: (depth, id) pairs + a second u64 array + point_list + the radix path's
@@ -44,7 +44,7 @@ def test_size_queries():
     P, W, H = 500_000, 1920, 1080
     per_instance = (lib.gsr_binning_bytes(40_000_000, P, W, H) - lib.gsr_binning_bytes(0, P, W, H)) / 40_000_000
     assert 24.0 <= per_instance <= 28.5, per_instance
-    assert lib.gsr_backward_scratch_bytes(40_000_000, W, H) <= 48 * 40_000_000 + 256
+    assert lib.gsr_backward_scratch_bytes(40_000_000, W, H) <= 36 * 40_000_000 + 256
 
 
 def test_set_variant_reports_failure():
