@@ -238,9 +238,14 @@ size_t gsr_backward_scratch_bytes(int64_t R, int W, int H)
 
 // Phase 1 shared by gsr_forward_geometry, gsr_forward and gsr_forward_params: `a` carries the inputs, the outputs inside the
 // geometry buffer are filled in here.  launch_geometry enqueues the two kernels, wait_geometry returns R.
-struct GeometryWait { bool mail = false; unsigned long long* mail_host = nullptr; uint32_t seq = 0; char* total_dev = nullptr; };
+struct GeometryWait {
+    bool mail = false; unsigned long long* mail_host = nullptr; uint32_t seq = 0; char* total_dev = nullptr;
+    unsigned long long* mail_dev = nullptr;  // handed to emit_partition_kernel when no scan kernel was launched (with_scan = false)
+};
 
-static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_bytes, GeometryWait* w, hipStream_t s)
+// with_scan = false: the caller enqueues the banded head right behind this (launch_render_head), whose first kernel scans the block sums
+// itself and publishes R -- no scan_blocks launch (one ~5 us kernel less on the critical path)
+static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_bytes, GeometryWait* w, hipStream_t s, bool with_scan = true)
 {
     const int P = a.P;
     const GeomLayout L = gsr_geom_layout(P);
@@ -249,12 +254,14 @@ static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_byte
     a.splat = (float*)(g + L.splat); a.cov3D = (float*)(g + L.cov3D); a.clamped = (uint8_t*)(g + L.clamped);
     a.tiles_touched = (uint32_t*)(g + L.tiles_touched); a.block_sums = (uint32_t*)(g + L.block_sums);
     a.row_block_sums = (uint32_t*)(g + L.row_block_sums);
+    a.zero64 = (uint32_t*)(g + L.band_count);
     { StageTimer t(GSR_STAGE_PREPROCESS, s); gsr_launch_preprocess(a, s); }
     const int nb = (P + 255) / 256;
     unsigned long long* mail_dev = nullptr;
     w->mail = gsr_variant("MAILBOX", 1) && mailbox_acquire(&w->mail_host, &mail_dev, &w->seq);
+    w->mail_dev = w->mail ? mail_dev : nullptr;
     w->total_dev = g + L.total;
-    {
+    if (with_scan) {
         StageTimer t(GSR_STAGE_SCAN, s);
         gsr_launch_scan_blocks2(nb, a.block_sums, (uint32_t*)(g + L.block_offsets), (uint32_t*)(g + L.total), a.row_block_sums,
                                 (uint32_t*)(g + L.row_block_offsets), w->mail ? mail_dev : nullptr, w->seq, (uint32_t*)(g + L.band_count), s);
@@ -326,7 +333,8 @@ int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float*
 
 // The stages of phase 2 that need neither R nor the R-sized arrays: instance offsets (emit) and the head of the tile binning.
 // gsr_forward / gsr_forward_params enqueue them BEFORE waiting for R, so the host round trip overlaps with GPU work.
-static void launch_render_head(int P, int W, int H, void* geom_buffer, void* binning_buffer, hipStream_t s)
+static void launch_render_head(int P, int W, int H, void* geom_buffer, void* binning_buffer, hipStream_t s,
+                               unsigned long long* mailbox = nullptr, uint32_t seq = 0)
 {
     const GeomLayout G = gsr_geom_layout(P);
     const BinLayout B = gsr_bin_layout(0, P, W, H);  // the offsets used here do not depend on R
@@ -335,8 +343,9 @@ static void launch_render_head(int P, int W, int H, void* geom_buffer, void* bin
     {   // per-Gaussian instance offsets (needed by the backward's gradient-row addressing), with the band partition when it applies
         StageTimer t(GSR_STAGE_EMIT, s);
         if (!gsr_launch_emit_partition(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched),
-                                       (const uint32_t*)(g + G.block_offsets), (uint32_t*)(g + G.point_offsets),
-                                       (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets),
+                                       (const uint32_t*)(g + G.block_sums), (const uint32_t*)(g + G.row_block_sums),
+                                       (uint32_t*)(g + G.total), (uint32_t*)(g + G.row_block_offsets) + (P + 255) / 256, mailbox, seq,
+                                       (uint32_t*)(g + G.point_offsets), (uint32_t*)(g + G.row_offsets),
                                        (uint32_t*)(g + G.wg_first), (uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), s))
             gsr_launch_emit(P, W, H, (float*)(g + G.splat), (const uint32_t*)(g + G.tiles_touched), (const uint32_t*)(g + G.block_offsets),
                             (uint32_t*)(g + G.point_offsets), (const uint32_t*)(g + G.row_block_offsets), (uint32_t*)(g + G.row_offsets),
@@ -440,10 +449,16 @@ static int forward_fused(const PreprocessArgs& a, const float* background, void*
                          hipStream_t s)
 {
     GeometryWait w;
-    int rc = launch_geometry(a, geom_buffer, geom_bytes, &w, s);
-    if (rc != 0) return rc;
     const bool early = can_launch_head_early(a.P, a.W, a.H, binning_buffer, binning_bytes);
-    if (early) launch_render_head(a.P, a.W, a.H, geom_buffer, binning_buffer, s);
+    // EMIT_SCAN (default): with the banded head enqueued right behind the preprocess kernel, its first kernel does the block scan and
+    // publishes R; the separate scan kernel is launched only where R must reach the host without that head
+    int nb_, bh_;
+    const bool emit_scan = early && gsr_variant("EMIT_SCAN", 1) && gsr_variant("MAILBOX", 1) &&
+                           gsr_band_geometry((a.W + GSR_TILE_X - 1) / GSR_TILE_X, (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y, &nb_, &bh_);
+    int rc = launch_geometry(a, geom_buffer, geom_bytes, &w, s, !emit_scan);
+    if (rc != 0) return rc;
+    // (without a mailbox slot wait_geometry copies the total that emit_partition_kernel's first workgroup stores)
+    if (early) launch_render_head(a.P, a.W, a.H, geom_buffer, binning_buffer, s, emit_scan ? w.mail_dev : nullptr, w.seq);
     rc = wait_geometry(w, num_rendered_host, s);
     if (rc != 0) return rc;
     const int64_t R = *num_rendered_host;

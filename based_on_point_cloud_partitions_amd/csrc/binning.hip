@@ -285,17 +285,39 @@ struct BandGeom { int gx, gy, T, nb, bh, tmax, cull; };  // bh = tile rows per b
 constexpr int PART_ITEMS = 2;
 __global__ void __launch_bounds__(SLICE_THREADS) emit_partition_kernel(int P, BandGeom G, float* __restrict__ splat,
                                                                         const uint32_t* __restrict__ tiles_touched,
-                                                                        const uint32_t* __restrict__ block_offsets,
+                                                                        const uint32_t* __restrict__ block_sums,
+                                                                        const uint32_t* __restrict__ row_block_sums,
+                                                                        uint32_t* __restrict__ total_out, uint32_t* __restrict__ row_total_out,
+                                                                        unsigned long long* mailbox, uint32_t seq,
                                                                         uint32_t* __restrict__ point_offsets,
-                                                                        const uint32_t* __restrict__ row_block_offsets,
                                                                         uint32_t* __restrict__ row_offsets,
                                                                         uint32_t* __restrict__ wg_first,
                                                                         uint32_t* __restrict__ band_count, uint32_t* __restrict__ band_list)
 {
     __shared__ uint32_t cnt[NB_MAX], base[NB_MAX];
     __shared__ uint32_t wtot[PART_ITEMS][16], wtot_r[PART_ITEMS][16];
+    __shared__ uint32_t s_red[4][16];
     if (threadIdx.x < NB_MAX) cnt[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Round 4: the block scan is done HERE -- every workgroup adds up the preprocess kernel's per-256-Gaussian sums (instances and
+    // gradient rows) in front of its own Gaussians and all of them (a few KB out of L2, two loads per thread at 500k Gaussians), so the
+    // single-workgroup scan_blocks_kernel, a launch of its own between preprocess and this kernel, is only needed where the host must
+    // know R before this kernel can run (api.hip).  Workgroup 0 publishes R in the host's mailbox word and stores the two totals.
+    uint32_t before = 0, before_r = 0, total = 0, total_r = 0;
+    {
+        const int nblk = (P + 255) >> 8, first_blk = (int)blockIdx.x * (PART_ITEMS * SLICE_THREADS / 256);
+        for (int i = threadIdx.x; i < nblk; i += SLICE_THREADS) {
+            const uint32_t v = block_sums[i], vr = row_block_sums[i];
+            total += v; total_r += vr;
+            if (i < first_blk) { before += v; before_r += vr; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            before += __shfl_xor(before, off, 64); before_r += __shfl_xor(before_r, off, 64);
+            total += __shfl_xor(total, off, 64); total_r += __shfl_xor(total_r, off, 64);
+        }
+        if (lane == 0) { s_red[0][wave] = before; s_red[1][wave] = before_r; s_red[2][wave] = total; s_red[3][wave] = total_r; }
+    }
     int b0[PART_ITEMS], b1[PART_ITEMS];
     uint32_t n[PART_ITEMS], nr[PART_ITEMS], incl[PART_ITEMS], incl_r[PART_ITEMS];
 #pragma unroll
@@ -322,18 +344,28 @@ __global__ void __launch_bounds__(SLICE_THREADS) emit_partition_kernel(int P, Ba
         if (lane == 63) { wtot[e][wave] = in; wtot_r[e][wave] = ir; }
     }
     __syncthreads();
+    before = before_r = total = total_r = 0;
+#pragma unroll
+    for (int w = 0; w < SLICE_THREADS / 64; w++) { before += s_red[0][w]; before_r += s_red[1][w]; total += s_red[2][w]; total_r += s_red[3][w]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *total_out = total;
+        *row_total_out = total_r;
+        if (mailbox) __hip_atomic_store(mailbox, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #pragma unroll
     for (int e = 0; e < PART_ITEMS; e++) {
         const int idx = (blockIdx.x * PART_ITEMS + e) * SLICE_THREADS + threadIdx.x;
         for (int b = b0[e]; b <= b1[e]; b++) atomicAdd(&cnt[b], 1u);
         if (idx < P) {
-            const int blk = idx >> 8;
-            uint32_t bs = block_offsets[blk], bs_r = row_block_offsets[blk];
-            for (int w = wave & ~3; w < wave; w++) { bs += wtot[e][w]; bs_r += wtot_r[e][w]; }
+            // instances / rows before this wave: the workgroup's base + the items before this one + the waves before this one
+            uint32_t bs = before, bs_r = before_r;
+            for (int e2 = 0; e2 < e; e2++)
+                for (int w = 0; w < SLICE_THREADS / 64; w++) { bs += wtot[e2][w]; bs_r += wtot_r[e2][w]; }
+            for (int w = 0; w < wave; w++) { bs += wtot[e][w]; bs_r += wtot_r[e][w]; }
             const uint32_t end = bs + incl[e], end_r = bs_r + incl_r[e];
             point_offsets[idx] = end;
             row_offsets[idx] = end_r;
-            gsr_part_store(wg_first, P, idx, end_r - nr[e], end_r, row_block_offsets[(P + 255) >> 8]);
+            gsr_part_store(wg_first, P, idx, end_r - nr[e], end_r, total_r);
             if (n[e] != 0) {
                 float* rec = splat + (size_t)idx * GSR_SPLAT_F;
                 rec[SP_ROWBASE] = __uint_as_float(end_r - nr[e]);
@@ -988,8 +1020,9 @@ size_t gsr_band_list_bytes(int P, int W, int H)
     return (size_t)G.nb * (size_t)(P > 0 ? P : 1) * 4 + GSR_BAND_COUNTERS * 4;  // id lists (+ 64 unused words in front)
 }
 
-bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                               uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* wg_first,
+bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_sums,
+                               const uint32_t* row_block_sums, uint32_t* total, uint32_t* row_total, unsigned long long* mailbox,
+                               uint32_t seq, uint32_t* point_offsets, uint32_t* row_offsets, uint32_t* wg_first,
                                uint32_t* band_count, uint32_t* band_mem, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
@@ -998,8 +1031,8 @@ bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t
     const BandGeom G = band_geom(gx, gy);
     // the band counters were zeroed by scan_blocks_kernel (preprocess.hip)
     hipLaunchKernelGGL(emit_partition_kernel, dim3((P + SLICE_THREADS * PART_ITEMS - 1) / (SLICE_THREADS * PART_ITEMS)), dim3(SLICE_THREADS), 0, s, P,
-                       G, splat, tiles_touched, block_offsets, point_offsets, row_block_offsets, row_offsets, wg_first, band_count,
-                       band_mem + GSR_BAND_COUNTERS);
+                       G, splat, tiles_touched, block_sums, row_block_sums, total, row_total, mailbox, seq, point_offsets, row_offsets, wg_first,
+                       band_count, band_mem + GSR_BAND_COUNTERS);
     return true;
 }
 

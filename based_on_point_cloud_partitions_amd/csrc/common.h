@@ -222,6 +222,7 @@ struct PreprocessArgs {
     // scene/gaussian_model.py:102-122 and the SH rows come from the two tensors features_dc [P][1][3] / features_rest [P][M-1][3]
     int raw;
     const float *features_dc, *features_rest;
+    uint32_t* zero64;  // the 64 band counters of the tile binning (zeroed here so that no kernel has to run in between just for that)
 };
 void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,
@@ -236,8 +237,10 @@ void gsr_launch_emit(int P, int W, int H, float* splat, const uint32_t* tiles_to
                      uint64_t* keys, uint32_t* vals, hipStream_t s);
 // banded tile binning: the instance / gradient-row offsets of gsr_launch_emit (no keys) and the per-band id lists in one pass
 // over the splat records; false (nothing launched) when the banded binning does not apply to this tile grid
-bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_offsets,
-                               uint32_t* point_offsets, const uint32_t* row_block_offsets, uint32_t* row_offsets, uint32_t* wg_first,
+// (it scans the preprocess kernel's block sums itself; mailbox != NULL: workgroup 0 also publishes R there, tagged with seq)
+bool gsr_launch_emit_partition(int P, int W, int H, float* splat, const uint32_t* tiles_touched, const uint32_t* block_sums,
+                               const uint32_t* row_block_sums, uint32_t* total, uint32_t* row_total, unsigned long long* mailbox,
+                               uint32_t seq, uint32_t* point_offsets, uint32_t* row_offsets, uint32_t* wg_first,
                                uint32_t* band_count, uint32_t* band_mem, hipStream_t s);
 // true (and the band count / height in tile rows) when the banded tile binning applies to this tile grid
 bool gsr_band_geometry(int gx, int gy, int* nb, int* bh);

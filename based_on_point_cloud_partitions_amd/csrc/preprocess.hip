@@ -65,6 +65,7 @@ struct PreprocessPtrs {
     float scale_modifier, tan_fovx, tan_fovy;
     int* __restrict__ radii; float* __restrict__ splat; float* __restrict__ cov3D; uint8_t* __restrict__ clamped;
     uint32_t* __restrict__ tiles_touched; uint32_t* __restrict__ block_sums; uint32_t* __restrict__ row_block_sums;
+    uint32_t* zero64;
 };
 
 // RAW: scales / rotations / opacities are the pre-activation parameters (exp / normalize / sigmoid applied here) and the
@@ -260,6 +261,7 @@ preprocess_kernel(PreprocessPtrs a, float focal_x, float focal_y, int gx, int gy
         a.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         a.row_block_sums[blockIdx.x] = rsum[0] + rsum[1] + rsum[2] + rsum[3];
     }
+    if (blockIdx.x == 0 && threadIdx.x < GSR_BAND_COUNTERS && a.zero64) a.zero64[threadIdx.x] = 0;  // filled by emit_partition_kernel's atomics
 }
 
 // Exclusive scan of the per-workgroup sums (single workgroup, 1024 threads, chunked with a carry).
@@ -403,6 +405,7 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     p.scale_modifier = a.scale_modifier; p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
     p.radii = a.radii; p.splat = a.splat; p.cov3D = a.cov3D; p.clamped = a.clamped; p.tiles_touched = a.tiles_touched;
     p.block_sums = a.block_sums; p.row_block_sums = a.row_block_sums; p.features_dc = a.features_dc; p.features_rest = a.features_rest;
+    p.zero64 = a.zero64;
     p.sh_direct = ((a.raw ? a.features_rest != nullptr : a.shs != nullptr) && a.M == 16 && a.D == 3 && gsr_variant("PRE_DIRECT", 1)) ? 1 : 0;
     const size_t lds = (((a.shs || a.raw) && !p.sh_direct) ? (size_t)256 * (3 * a.M + 1) * 4 : 0) + (size_t)gsr_variant("LDS_PAD", 0);
     if (a.raw)

@@ -10,7 +10,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = dict(QUAD=1, CULL=1, BIN=2, LPT=1, MAILBOX=1, BWD_FASTEXP=1, BWD_NQ=0, KEYS=0, WAVE8X8=1, EARLY=1, BANDS=8,
-                GB_BLOCK=128, PRE_DIRECT=1, GB_DIRECT=1, GB_RK=1, BWD_PADLDS=0, FWD_PADLDS=0, GB_BALANCED=1, MID_HINT=1)
+                GB_BLOCK=128, PRE_DIRECT=1, GB_DIRECT=1, GB_RK=1, BWD_PADLDS=0, FWD_PADLDS=0, GB_BALANCED=1, MID_HINT=1, EMIT_SCAN=1)
 ALTERNATIVES = [
     dict(QUAD=0),                 # forward: every wave walks the whole tile list
     dict(QUAD=0, CULL=0),         # ... over the reference's lists
@@ -34,6 +34,9 @@ ALTERNATIVES = [
     dict(GB_BALANCED=0),          # per-Gaussian backward: 128 consecutive Gaussians per workgroup, every thread adds its own rows
     dict(GB_BALANCED=0, GB_BLOCK=256),
     dict(GB_BALANCED=0, GB_DIRECT=0),
+    dict(EMIT_SCAN=0),            # block scan as its own launch (scan_blocks_kernel) instead of inside emit_partition_kernel
+    dict(EMIT_SCAN=0, MAILBOX=0),
+    dict(EMIT_SCAN=1, MAILBOX=0),
     dict(MID_HINT=0),             # tile_sort_mid_kernel launched every frame
     dict(MID_HINT=2),             # ... never: lists of more than 2048 entries are left to tile_sort_small_kernel's in-place network
     dict(BWD_NQ=2, BWD_PADLDS=6144),  # the occupancy experiments' switches: fewer workgroups per CU, same results
