@@ -19,7 +19,7 @@ if kt:
         name=r["Kernel_Name"].replace("(anonymous namespace)::","").replace("void ","").split("(")[0]
         dur[name].append(float(r["End_Timestamp"])-float(r["Start_Timestamp"]))
 for k,v in per.items():
-    if not any(s in k for s in ("render_", "gaussian_backward", "row_", "preprocess", "tile_")): continue
+    if not any(s in k for s in ("render_", "gaussian_backward", "row_", "preprocess", "tile_", "emit_")): continue
     d={c:sum(x)/len(x) for c,x in v.items()}
     print(k[:44].ljust(44), "dur_us=%.1f" % (sum(dur[k])/max(1,len(dur[k]))/1e3), " ".join("%s=%.4g" % (c, d[c]) for c in sorted(d)))
 PY

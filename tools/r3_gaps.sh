@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel timeline of a few steps: per-step busy time, gaps between consecutive kernels; usage: tools/r3_gaps.sh <tag>
 tag=${1:-gaps}; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $out -o kt -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $out -o kt -- python3 bench.py --steps 64 --warmup 4 --no-cpu-baseline --no-stage-timers --dist off --spinup-ms 600 > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
 python3 - <<PY
 import csv,glob
 f=glob.glob("$out/**/kt_kernel_trace.csv",recursive=True)[0]
