@@ -793,8 +793,8 @@ def main():
                              "hbm": {"algorithmic_bytes": 120 * P, "achieved": round(120 * P / 1e9 / (knn_ms * 1e-3), 1), "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": round(120 * P / 1e9 / (knn_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                              "note": "whole distCUDA2 call (min/max, Morton codes, radix sort, gather, box AABBs, search); exact 3-NN: a wave is one "
-                                     "64-point box of Morton-sorted queries, scans its own box first, then walks the box groups outward and "
-                                     "scans from LDS every box one of its lanes cannot reject (no workgroup barrier)"},
+                                     "64-point box of Morton-sorted queries, scans its own box first, then walks a four-level AABB tree outward "
+                                     "(tops, groups, boxes, 16-point quarters) and scans from LDS what its lanes cannot reject (no workgroup barrier)"},
             "rccl_world_size": len(dist_state["ranks_seen"]), "rccl_ranks_seen": dist_state["ranks_seen"],
             "collective_backend": (dist.get_backend() if dist is not None else None), "collective_init_error": dist_state["error"],
             "collective_init": ("before the warm-up (N > 1: the timed region is bracketed by its barriers)" if world > 1 else
