@@ -345,15 +345,19 @@ def full_step_timing(args, rasterizers, g, dL, H, W, dev):
     return res
 
 
+STEP_SOURCES = ("api.hip", "preprocess.hip", "binning.hip", "radix_sort.hip", "render_forward.hip", "render_backward.hip",
+                "gaussian_backward.hip", "common.h")
+
+
 def kernel_source_hash():
-    """Identifies the kernel build a measurement belongs to: sha1 over the HIP sources (they travel with the repo snapshot)."""
-    import glob
+    """Identifies the kernel build a measurement belongs to: sha1 over the HIP sources of the raster step (they travel with the repo
+    snapshot; kNN / loss / Adam / appearance sources do not enter: their kernels are not part of the step the PMC profile describes)."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "based_on_point_cloud_partitions_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for name in STEP_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:12]
 
 
