@@ -127,7 +127,7 @@ def _oracle_step(g, cam, dL):
     return t1 - t0, time.perf_counter() - t1, st
 
 
-def cpu_baseline(cfg, g, cams, dL, n_steps=4):
+def cpu_baseline(cfg, g, cams, dL, n_steps=16):
     """The oracle (a CPU port of the reference algorithm; the reference has no CPU path) on a bounded sample of the same workload:
     `n_steps` raster steps (cameras 0..n_steps-1) with every host thread, plus -- SURVEY.md §8(d) -- one step of the small
     reference-runnable case (cfg1: 10k Gaussians, 256x256) with one thread and with all of them, so the OpenMP scaling is visible."""
