@@ -140,10 +140,10 @@ def partition_origin_box(rank, world_size, cell=(8.0, 8.0), grid_cols=4):
     return (x0, x0 + cell[0], y0, y0 + cell[1])
 
 
-def make_partition(rank, world_size, P, seed=0, overlap=0.1):
+def make_partition(rank, world_size, P, seed=0, overlap=0.1, cell=(8.0, 8.0)):
     """Gaussians + camera-ring centre of one partition: the box is expanded by `overlap` on every side
-    (scene/ptgs/shen_partation_densify.py:182-252 expands partitions by 10 %)."""
-    x0, x1, y0, y1 = partition_origin_box(rank, world_size)
+    (scene/ptgs/shen_partation_densify.py:182-252 expands partitions by 10 %).  `cell` = the XY size of an origin box."""
+    x0, x1, y0, y1 = partition_origin_box(rank, world_size, cell=cell)
     ex, ey = overlap * (x1 - x0), overlap * (y1 - y0)
     g = make_gaussians(P, seed=seed + 1000 * rank, box_min=(x0 - ex, y0 - ey, -1.0), box_max=(x1 + ex, y1 + ey, 1.0))
     centre = (0.5 * (x0 + x1), 0.5 * (y0 + y1), 0.0)

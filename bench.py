@@ -9,7 +9,10 @@ SH colour, tile binning (prefix sum, key emission, 64-bit radix sort, tile range
 full backward for a fixed synthetic dL/dcolor -- what train.py:107 + :118 spend in the rasterizer.
 Workload at N = 1: BASELINE.json configs[1] (one partition of 500,000 random-init Gaussians, 1920x1080, SH degree 3,
 16 cameras on a ring); at N > 1 every rank owns its own 500k-Gaussian partition (weak scaling, no data-path
-collective: the reference trains partitions independently, auto_train.py:22-51).
+collective: the reference trains partitions independently, auto_train.py:22-51).  A rank's partition fills the same volume as the
+N = 1 scene -- its origin box is 8/1.2 wide, so the box expanded by the reference's 10 % per side is 8 x 8 x 2 around its own camera
+ring -- with its own seed: the per-GPU work is the same distribution at every N (R = 3.70 M instances for camera 0 at N = 1, 3.70 +-
+0.01 M on the ranks of N = 8; with 8-wide origin boxes, as until round 4, a rank had 15 % fewer).
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -20,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PARTITION_CELL = (8.0 / 1.2, 8.0 / 1.2)  # origin box of a rank's partition at N > 1; expanded by 10 % per side it is the N = 1 scene's 8 x 8
 
 
 def _requested_gpus(argv):
@@ -441,7 +445,7 @@ def main():
         g = syn.make_gaussians(P, seed=0)
         centre = (0.0, 0.0, 0.0)
     else:
-        g, centre, _box = syn.make_partition(rank, world, P, seed=0)
+        g, centre, _box = syn.make_partition(rank, world, P, seed=0, cell=PARTITION_CELL)
     if args.order == "morton":
         q = ((g.xyz - g.xyz.min(0).values) / (g.xyz.max(0).values - g.xyz.min(0).values + 1e-9) * 1023.0).to(torch.int64)
 
@@ -649,7 +653,7 @@ def main():
     from based_on_point_cloud_partitions_amd import evaluate, merge
     boxes = []
     for r_ in range(world):
-        bx0, bx1, by0, by1 = syn.partition_origin_box(r_, world)
+        bx0, bx1, by0, by1 = syn.partition_origin_box(r_, world, cell=PARTITION_CELL)
         boxes.append((bx0, by0, bx1, by1))
     with torch.no_grad():
         merge.dedup_first_lexicographic(torch.rand(4096, merge.ROW, device=dev))  # (loads the sort kernels: dedup_ms is the algorithm's time)
