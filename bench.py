@@ -376,9 +376,10 @@ def main():
                     help="memory order of the Gaussians: the workload's own (random, BASELINE.md) or sorted by the Morton code of xyz "
                          "(what a trainer gets by re-ordering its model at densification time; not the headline workload)")
     ap.add_argument("--no-stage-timers", action="store_true", help="time the region without per-stage HIP events")
-    ap.add_argument("--dist", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--dist", default="auto", choices=["auto", "on", "off", "early"],
                     help="process group at N = 1: auto = bring up a world-size-1 RCCL group (continue without one if it fails), "
-                         "on = required, off = none; N > 1 always has one")
+                         "on = required, off = none, early = required and BEFORE the warm-up, with every barrier of an N > 1 run "
+                         "(a one-GPU rehearsal of the N > 1 ordering); N > 1 always has one")
     ap.add_argument("--spinup-ms", type=float, default=6000.0,
                     help="upper limit of the untimed spin-up before the warm-up: batches of 64 steps run until four in a row bring no "
                          "improvement of 0.5 %% (at least 0.5 s).  A fresh box's GPU reaches its steady clocks only after a second or more of "
@@ -425,7 +426,7 @@ def main():
             else:
                 dist_.init_process_group(backend, **kw)
         except Exception as exc:  # noqa: BLE001 -- only tolerable at world 1, where no exchange is needed
-            if world > 1 or args.dist == "on":
+            if world > 1 or args.dist in ("on", "early"):
                 raise
             dist_state["error"] = f"{type(exc).__name__}: {exc}"
             return None
@@ -437,7 +438,7 @@ def main():
         dist_state["dist"] = dist_
         return dist_
 
-    dist = init_dist() if world > 1 else None
+    dist = init_dist() if world > 1 or args.dist == "early" else None
 
     cfg = syn.CONFIGS[args.config]
     P, W, H = cfg["P"], cfg["W"], cfg["H"]
@@ -542,7 +543,7 @@ def main():
     spinup = None
     # N > 1: at least 2 s -- the process group came up before the warm-up, and the seconds behind librccl's first use are slow on a
     # fresh box (see init_dist above); the collectives the timed region uses are warmed here too
-    min_spin = 0.5 if world == 1 else min(2.0, 1e-3 * args.spinup_ms)
+    min_spin = 0.5 if dist is None else min(2.0, 1e-3 * args.spinup_ms)
     if dist is not None:
         for _ in range(3):
             dist.barrier()
@@ -565,7 +566,7 @@ def main():
         spinup = {"steps": k, "ms": round(1e3 * (time.perf_counter() - t_spin), 1), "first_batch_ms_per_step": batches[0],
                   "last_batch_ms_per_step": batches[-1]}
         untimed_steps += k
-        if dist is not None and world > 1:  # ranks leave their spin-up at different times: align, then 32 more steps so that nobody starts cold
+        if dist is not None:  # ranks leave their spin-up at different times: align, then 32 more steps so that nobody starts cold
             dist.barrier()
             for i in range(32):
                 step(i)
@@ -636,7 +637,7 @@ def main():
     torch.cuda.synchronize()
     knn_ms = round(1e3 * (time.perf_counter() - tk) / 5, 3)
 
-    if world == 1 and (args.dist == "on" or (args.dist == "auto" and backend == "nccl")):
+    if world == 1 and dist is None and (args.dist == "on" or (args.dist == "auto" and backend == "nccl")):
         # N = 1: the world-size-1 RCCL group comes up here -- behind the timed region and every other timing of this script -- and the
         # collectives of an N > 1 run follow through it: all-reduce (MAX) of the timing, merge all-gathers, evaluation all-reduce, barrier
         dist = init_dist()
@@ -806,6 +807,7 @@ def main():
             "rccl_world_size": len(dist_state["ranks_seen"]), "rccl_ranks_seen": dist_state["ranks_seen"],
             "collective_backend": (dist.get_backend() if dist is not None else None), "collective_init_error": dist_state["error"],
             "collective_init": ("before the warm-up (N > 1: the timed region is bracketed by its barriers)" if world > 1 else
+                                "before the warm-up (--dist early: the ordering of an N > 1 run on one GPU)" if args.dist == "early" else
                                 "after the timed region (N = 1: no rank to align with; the later collectives -- all-reduce of the "
                                 "timing, merge all-gather, evaluation all-reduce, barrier -- run through it)"),
             "merge": {"world_size": ev["world_size"], "rows_per_rank_after_crop": ev["counts"], "merged_rows": merged_rows,
