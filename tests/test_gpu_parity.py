@@ -526,6 +526,61 @@ def test_runs_on_a_non_default_stream():
     assert_forward_bit_exact(ctx, st)
 
 
+def test_two_host_threads_on_two_streams():
+    """Two host threads, each with its own HIP stream and its own scene (an evaluation render beside a training step, say): every
+    call's num_rendered travels through its own slot of the library's pinned mailbox and all other state lives in the caller's
+    buffers, so each thread must see exactly what it sees alone -- image bit-exact against the oracle, gradients bitwise equal to
+    the single-threaded run -- on every one of its iterations."""
+    import threading
+
+    from based_on_point_cloud_partitions_amd import GaussianRasterizer
+
+    dev = torch.device("cuda", 0)
+    jobs = []
+    for k, (P, W, H, focal, seed, lo, hi) in enumerate([(6000, 208, 144, 120.0, 21, 0.01, 0.1), (2500, 97, 251, 150.0, 22, 0.004, 0.3)]):
+        g, cam = scene(P, W, H, focal, seed=seed, scale_lo=lo, scale_hi=hi, cam_index=k)
+        st = oracle_forward(g, cam)
+        dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(40 + k)).to(dev)
+        params = [t.to(dev).requires_grad_(True) for t in (g.xyz, g.opacities, g.shs, g.scales, g.rotations)]
+        jobs.append(dict(rast=GaussianRasterizer(hip_settings(cam, (0.0, 0.0, 0.0), 3, device=dev)), st=st, dL=dL, params=params))
+
+    def run_once(job):
+        xyz, opac, shs, scales, rots = job["params"]
+        ss = torch.zeros_like(xyz, requires_grad=True)
+        image, radii = job["rast"](means3D=xyz, means2D=ss, opacities=opac, shs=shs, scales=scales, rotations=rots)
+        grads = torch.autograd.grad(image, [xyz, ss, opac, shs, scales, rots], job["dL"])
+        return [image.detach().clone(), radii.clone()] + [t.clone() for t in grads]
+
+    for job in jobs:  # alone, on the default stream
+        job["want"] = run_once(job)
+        assert np.array_equal(job["want"][0].cpu().numpy(), job["st"]["out_color"])
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(job, iters):
+        try:
+            torch.cuda.set_device(dev)
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for it in range(iters):
+                    got = run_once(job)
+                    stream.synchronize()
+                    for a, b in zip(got, job["want"]):
+                        if not torch.equal(a, b):
+                            errors.append(f"iteration {it}: a result differs from the single-threaded run")
+                            return
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(job, 40)) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+
+
 # ---------------------------------------------------------------------------------------------------------
 # radix sort and kNN
 # ---------------------------------------------------------------------------------------------------------
