@@ -526,6 +526,20 @@ def test_runs_on_a_non_default_stream():
     assert_forward_bit_exact(ctx, st)
 
 
+def test_non_finite_inputs_are_memory_safe(tile_list_mode):
+    """NaN, +-Inf, 1e30, denormals, negative scales, zero quaternions and opacities outside [0, 1] scattered over every input (what a
+    diverging optimisation produces): the reference's behaviour on such a Gaussian is undefined, but forward, backward and kNN must
+    return, the binning must stay self-consistent and the untouched Gaussians bit-exact (tools/r4_poison.py holds the checks)."""
+    import importlib.util
+
+    if tile_list_mode != "culled":
+        pytest.skip("the tool runs both tile-list modes itself")
+    spec = importlib.util.spec_from_file_location("r4_poison", os.path.join(os.path.dirname(G), "..", "tools", "r4_poison.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(6, quiet=True) == 6
+
+
 def test_two_host_threads_on_two_streams():
     """Two host threads, each with its own HIP stream and its own scene (an evaluation render beside a training step, say): every
     call's num_rendered travels through its own slot of the library's pinned mailbox and all other state lives in the caller's
