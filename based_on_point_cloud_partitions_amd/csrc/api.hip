@@ -45,8 +45,11 @@ struct StageTimer {
         : stage(stage_), s(s_), on(g_prof && ((g_prof_mask >> stage_) & 1u)), count(count_)
     {
         if (on) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+            // timing-only events: without the system-scope fence a default event carries (a write-back and invalidation of the caches
+            // when it completes -- paid by the kernel behind it).  GSR_EVENT_FENCE=1 brings the default events back (A/B).
+            const unsigned flags = gsr_variant("EVENT_FENCE", 0) ? hipEventDefault : hipEventDisableSystemFence;
+            hipEventCreateWithFlags(&a, flags);
+            hipEventCreateWithFlags(&b, flags);
             hipEventRecord(a, s);
         }
     }
