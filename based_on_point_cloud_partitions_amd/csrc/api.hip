@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -244,7 +245,9 @@ size_t gsr_backward_scratch_bytes(int64_t R, int W, int H)
 struct GeometryWait {
     bool mail = false; unsigned long long* mail_host = nullptr; uint32_t seq = 0; char* total_dev = nullptr;
     unsigned long long* mail_dev = nullptr;  // handed to emit_partition_kernel when no scan kernel was launched (with_scan = false)
+    const uint32_t* trap_dev = nullptr; uint32_t trap_tag = 0;  // prefiltered: the word a culled point stamps with this call's tag
 };
+std::atomic<uint32_t> g_trap_tag{0};
 
 // with_scan = false: the caller enqueues the banded head right behind this (launch_render_head), whose first kernel scans the block sums
 // itself and publishes R -- no scan_blocks launch (one ~5 us kernel less on the critical path)
@@ -258,6 +261,12 @@ static int launch_geometry(PreprocessArgs a, void* geom_buffer, size_t geom_byte
     a.tiles_touched = (uint32_t*)(g + L.tiles_touched); a.block_sums = (uint32_t*)(g + L.block_sums);
     a.row_block_sums = (uint32_t*)(g + L.row_block_sums);
     a.zero64 = (uint32_t*)(g + L.band_count);
+    if (a.prefiltered) {  // the third of the four words at L.total; tags are non-zero and differ from call to call: no zeroing needed
+        uint32_t tag = ++g_trap_tag;
+        if (tag == 0) tag = ++g_trap_tag;
+        a.trap_flag = (uint32_t*)(g + L.total) + 2; a.trap_tag = tag;
+        w->trap_dev = a.trap_flag; w->trap_tag = tag;
+    }
     { StageTimer t(GSR_STAGE_PREPROCESS, s); gsr_launch_preprocess(a, s); }
     const int nb = (P + 255) / 256;
     unsigned long long* mail_dev = nullptr;
@@ -283,6 +292,15 @@ static int wait_geometry(const GeometryWait& w, int64_t* num_rendered_host, hipS
         if (e != hipSuccess) return fail(-100, "forward_geometry: %s", hipGetErrorString(e));
     }
     *num_rendered_host = (int64_t)total;
+    if (w.trap_dev) {
+        // prefiltered = true: the reference's kernel prints this message and traps when the frustum test rejects a point
+        // (auxiliary.h:154-160), which ends the process's CUDA context; here the call fails with the same words and the context lives
+        uint32_t stamp = 0;
+        hipError_t e = hipMemcpyAsync(&stamp, w.trap_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(-100, "forward_geometry: %s", hipGetErrorString(e));
+        if (stamp == w.trap_tag) return fail(-6, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
     return check_hip("forward_geometry");
 }
 
@@ -326,11 +344,11 @@ int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float*
                          int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* geom_buffer,
                          size_t geom_bytes, int64_t* num_rendered_host, void* stream)
 {
-    (void)prefiltered;  // only selects a device-side trap in the reference (auxiliary.h:156-160)
     PreprocessArgs a;
     const int rc = make_std_args(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                  viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, geom_buffer, num_rendered_host, &a);
     if (rc != 0) return rc < 0 ? rc : 0;
+    a.prefiltered = prefiltered != 0;
     return run_geometry(a, geom_buffer, geom_bytes, num_rendered_host, (hipStream_t)stream);
 }
 
@@ -477,11 +495,11 @@ int gsr_forward(int P, int D, int M, const float* background, const float* means
                 void* binning_buffer, size_t binning_bytes, void* image_buffer, size_t image_bytes, float* out_color,
                 int64_t* num_rendered_host, void* stream)
 {
-    (void)prefiltered;
     PreprocessArgs a;
     const int rc = make_std_args(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                  viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, geom_buffer, num_rendered_host, &a);
     if (rc != 0) return rc < 0 ? rc : 0;
+    a.prefiltered = prefiltered != 0;
     return forward_fused(a, background, geom_buffer, geom_bytes, binning_buffer, binning_bytes, image_buffer, image_bytes, out_color,
                          num_rendered_host, (hipStream_t)stream);
 }

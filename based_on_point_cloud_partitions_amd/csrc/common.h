@@ -223,6 +223,10 @@ struct PreprocessArgs {
     int raw;
     const float *features_dc, *features_rest;
     uint32_t* zero64;  // the 64 band counters of the tile binning (zeroed here so that no kernel has to run in between just for that)
+    // prefiltered (auxiliary.h:156-160: the reference traps when a point is culled although the caller promised none would be): a point that
+    // fails the near-plane test stores trap_tag -- this call's non-zero tag, so the word never needs zeroing -- into *trap_flag (NULL: off)
+    int prefiltered = 0;  // host side: launch_geometry (api.hip) turns it into the two fields below
+    uint32_t* trap_flag = nullptr; uint32_t trap_tag = 0;
 };
 void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 void gsr_launch_scan_blocks(int nblocks, const uint32_t* block_sums, uint32_t* block_offsets, uint32_t* total,

@@ -66,6 +66,7 @@ struct PreprocessPtrs {
     int* __restrict__ radii; float* __restrict__ splat; float* __restrict__ cov3D; uint8_t* __restrict__ clamped;
     uint32_t* __restrict__ tiles_touched; uint32_t* __restrict__ block_sums; uint32_t* __restrict__ row_block_sums;
     uint32_t* zero64;
+    uint32_t* trap_flag; uint32_t trap_tag;
 };
 
 // RAW: scales / rotations / opacities are the pre-activation parameters (exp / normalize / sigmoid applied here) and the
@@ -240,6 +241,8 @@ preprocess_kernel(PreprocessPtrs a, float focal_x, float focal_y, int gx, int gy
                     }
                 }
             }
+        } else if (a.trap_flag && tz <= 0.2f) {
+            *a.trap_flag = a.trap_tag;  // "Point is filtered although prefiltered is set" (auxiliary.h:154-160); the host raises
         }
         float4* rec = reinterpret_cast<float4*>(a.splat + (size_t)idx * GSR_SPLAT_F);
         rec[0] = rec0; rec[1] = rec1; rec[2] = rec2; rec[3] = rec3;
@@ -406,6 +409,7 @@ void gsr_launch_preprocess(const PreprocessArgs& a, hipStream_t s)
     p.radii = a.radii; p.splat = a.splat; p.cov3D = a.cov3D; p.clamped = a.clamped; p.tiles_touched = a.tiles_touched;
     p.block_sums = a.block_sums; p.row_block_sums = a.row_block_sums; p.features_dc = a.features_dc; p.features_rest = a.features_rest;
     p.zero64 = a.zero64;
+    p.trap_flag = a.trap_flag; p.trap_tag = a.trap_tag;
     p.sh_direct = ((a.raw ? a.features_rest != nullptr : a.shs != nullptr) && a.M == 16 && a.D == 3 && gsr_variant("PRE_DIRECT", 1)) ? 1 : 0;
     const size_t lds = (((a.shs || a.raw) && !p.sh_direct) ? (size_t)256 * (3 * a.M + 1) * 4 : 0) + (size_t)gsr_variant("LDS_PAD", 0);
     if (a.raw)

@@ -44,7 +44,11 @@ size_t gsr_backward_scratch_bytes(int64_t R, int W, int H);
 
 /* Phase 1 of CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:198-285): frustum cull, covariance
  * projection, SH colour, tiles_touched and its prefix sum.  Writes radii[P] and *num_rendered_host (host
- * pointer; the call waits for the prefix sum to read it, like the reference's cudaMemcpy at :281). */
+ * pointer; the call waits for the prefix sum to read it, like the reference's cudaMemcpy at :281).
+ * prefiltered != 0 (also in gsr_forward): the caller promises that no point fails the near-plane test; where one does, the
+ * reference's kernel prints "Point is filtered although prefiltered is set. This shouldn't happen!" and traps
+ * (auxiliary.h:154-160) -- here the call returns -6 with that message in gsr_last_error() (one more stream synchronisation per
+ * forward in this mode; the reference's callers pass false, gaussian_renderer/__init__.py:47). */
 int gsr_forward_geometry(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                          const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
                          const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,

@@ -526,6 +526,37 @@ def test_runs_on_a_non_default_stream():
     assert_forward_bit_exact(ctx, st)
 
 
+def test_prefiltered_raises_where_the_reference_traps():
+    """prefiltered=True promises that the frustum test rejects no point (auxiliary.h:154-160: the reference prints a message and
+    __trap()s otherwise).  All points in front of the near plane: same result as prefiltered=False; one behind the camera: GsrError with
+    the reference's words, and the next call works (the reference's trap would have ended the context)."""
+    from based_on_point_cloud_partitions_amd import GaussianRasterizer, _lib
+
+    P, W, H = 3000, 160, 120
+    g, cam = scene(P, W, H, 100.0, seed=12, scale_lo=0.01, scale_hi=0.08)
+    st = oracle_forward(g, cam)
+    assert (st["depths"][st["radii"] > 0] > 0.2).all()
+    dev = "cuda"
+    args = dict(means3D=g.xyz.to(dev), means2D=torch.zeros(P, 3, device=dev), opacities=g.opacities.to(dev), shs=g.shs.to(dev),
+                scales=g.scales.to(dev), rotations=g.rotations.to(dev))
+    plain = hip_settings(cam, (0.0, 0.0, 0.0), 3, device=dev)
+    pre = plain._replace(prefiltered=True)
+    img0, radii0 = GaussianRasterizer(plain)(**args)
+    img1, radii1 = GaussianRasterizer(pre)(**args)          # the ring camera sees every point in front of its near plane
+    assert torch.equal(img0, img1) and torch.equal(radii0, radii1)
+    assert np.array_equal(img1.cpu().numpy(), st["out_color"])
+    behind = dict(args)
+    xyz = g.xyz.clone()
+    xyz[1234] = cam.camera_center + 0.5 * (cam.camera_center - torch.zeros(3))  # half a camera distance behind the camera
+    behind["means3D"] = xyz.to(dev)
+    with pytest.raises(_lib.GsrError, match="Point is filtered although prefiltered is set"):
+        GaussianRasterizer(pre)(**behind)
+    img2, _ = GaussianRasterizer(plain)(**behind)            # prefiltered=False: the point is simply culled
+    torch.cuda.synchronize()
+    img3, radii3 = GaussianRasterizer(pre)(**args)           # and the library is fine afterwards
+    assert torch.equal(img3, img0) and torch.equal(radii3, radii0)
+
+
 def test_non_finite_inputs_are_memory_safe(tile_list_mode):
     """NaN, +-Inf, 1e30, denormals, negative scales, zero quaternions and opacities outside [0, 1] scattered over every input (what a
     diverging optimisation produces): the reference's behaviour on such a Gaussian is undefined, but forward, backward and kNN must
