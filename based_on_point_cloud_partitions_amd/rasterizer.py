@@ -58,7 +58,7 @@ def _prep(t, device, what):
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return _lib.stream_ptr(device)
 
 
 def _require_hip(t, what):
@@ -77,7 +77,7 @@ def rasterize_gaussians_forward(background, means3D, colors, opacity, scales, ro
     lib = _lib.load()
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         # P > 0: every pixel and every radius is written by the kernels; P == 0: nothing runs and both stay zero
         # (torch::full(0.0) in the reference, rasterize_points.cu:68-69)
         alloc = torch.empty if P != 0 else torch.zeros
@@ -134,7 +134,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
     f = dict(dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         if P == 0:
             z = lambda *shape: torch.zeros(shape, **f)
             return z(P, 3), z(P, NUM_CHANNELS), z(P, 1), z(P, 3), z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
@@ -174,7 +174,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     P = means3D.size(0)
     present = torch.zeros((P,), dtype=torch.bool, device=dev)
     if P != 0:
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             m, vm, pm = _prep(means3D, dev, "means3D"), _prep(viewmatrix, dev, "viewmatrix"), _prep(projmatrix, dev, "projmatrix")
             _lib.check(lib.gsr_mark_visible(P, _ptr(m), _ptr(vm), _ptr(pm), ctypes.c_void_p(present.data_ptr()), _stream(dev)),
                        "gsr_mark_visible")
@@ -317,7 +317,7 @@ def debug_export(P, R, W, H, geomBuffer, binningBuffer, imgBuffer):
                ranges=torch.zeros((T, 2), dtype=torch.int32, device=dev), final_T=torch.zeros((H, W), **f),
                n_contrib=torch.zeros((H, W), dtype=torch.int32, device=dev))
     if P:
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             order = ["means2D", "depths", "conic_opacity", "rgb", "cov3D", "clamped", "tiles_touched", "point_offsets",
                      "keys_sorted", "point_list", "ranges", "final_T", "n_contrib"]
             _lib.check(lib.gsr_debug_export(P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imgBuffer),

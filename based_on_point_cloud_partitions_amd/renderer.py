@@ -39,7 +39,7 @@ def rasterize_gaussian_params_forward(background, xyz, features_dc, features_res
     for t, n, what in ((opacity, P, "opacity"), (scaling, 3 * P, "scaling"), (rotation, 4 * P, "rotation")):
         if t.numel() != n:
             raise _lib.GsrError(f"{what} has {t.numel()} elements, expected {n}")
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         alloc = torch.empty if P != 0 else torch.zeros
         out_color = alloc((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
         radii = alloc((P,), dtype=torch.int32, device=dev)
@@ -90,7 +90,7 @@ def rasterize_gaussian_params_backward(background, xyz, radii, features_dc, feat
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     Mrest = features_rest.size(1)
     f = dict(dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         if P == 0:
             z = lambda *shape: torch.zeros(shape, **f)
             return z(P, 3), z(P, 3), z(P, 1, 3), z(P, Mrest, 3), z(P, 1), z(P, 3), z(P, 4)
