@@ -421,7 +421,7 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
             StageTimer t(GSR_STAGE_SORT, s, false);
             gsr_launch_tile_binning_tail(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
                                          (uint32_t*)(b + B.order), ranges, (const uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), ka, va,
-                                         gsr_variant("KEYS", 0) ? kb : nullptr, hint, hint_seq, launch_mid, s);
+                                         gsr_variant("KEYS", 0) ? kb : nullptr, kb, hint, hint_seq, launch_mid, s);
             point_list = va;
         } else {
         {

@@ -939,13 +939,106 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
 
 // (5a') lists of more than 2048 entries: up to 8192 (dense scenes: the 2M-Gaussian configuration has a mean list length of ~1900): the same
 // bucket sort with 1024 threads and 96 KB of LDS; the bitonic network took 0.8 ms per frame there.
+// A list longer than the LDS budget (n > BUCKET_CAP_MID; a dense or distant region behind one tile: every second tile of a 6 M-Gaussian
+// scene at 1080p).  Two levels: the depth bits are mapped monotonically onto NB coarse buckets of ~1-2 k entries (counting sort through LDS
+// counters: three reads of the list and one write, into `scratch` -- the second key array of the binning buffer, which this path does not
+// use otherwise), then every coarse bucket is a list of its own for bucket_sort_tile, which ranks on the full (depth, id) key and writes
+// its entries at their final positions; the buckets are in depth order, so their concatenation is the sorted list.  Rounds 1-3 ran the
+// bitonic network in place in HBM here (four active waves, log^2 n passes: 9 ms for a list of 125 k entries, 4.6 of the 8 ms of a step on
+// 6 M Gaussians); that network is now only the fallback for a coarse bucket that is itself too long for LDS (a run of equal depths).
+// In KEYS mode keys_sorted IS scratch: a coarse bucket's sort loads all its keys before it stores any (bucket_sort_tile), and its stores
+// stay inside its own segment.
+__device__ __forceinline__ void giant_list_sort(BucketSortLds<BUCKET_CAP_MID, 1024>& L, uint32_t* s_start, uint32_t tile, uint32_t r0, uint32_t n,
+                                                const unsigned long long* __restrict__ bins, unsigned long long* scratch,
+                                                uint32_t* __restrict__ point_list, unsigned long long* keys_sorted)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long* seg = bins + r0;
+    uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t d = (uint32_t)(seg[i] >> 32);
+        dmin = min(dmin, d); dmax = max(dmax, d);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, off, 64));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
+    }
+    uint32_t NB = 2;
+    while (NB < (n + 2047u) / 2048u) NB <<= 1;
+    if (NB > (uint32_t)BUCKET_CAP_MID) NB = (uint32_t)BUCKET_CAP_MID;
+    if (lane == 0) { L.red[wave] = dmin; L.red[16 + wave] = dmax; }
+    for (uint32_t b = tid; b <= NB; b += 1024) L.cnt[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; w++) { dmin = min(dmin, L.red[w]); dmax = max(dmax, L.red[16 + w]); }
+    const float inv = (float)NB / ((float)(dmax - dmin) + 1.0f);  // monotone, as in bucket_sort_tile
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t d = (uint32_t)(seg[i] >> 32);
+        atomicAdd(&L.cnt[min(NB - 1, (uint32_t)((float)(d - dmin) * inv))], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the NB counts: thread t owns buckets [t * E, t * E + E), E = max(1, NB / 1024) <= 8
+    const uint32_t E = NB >= 1024u ? NB / 1024u : 1u;
+    uint32_t c[8], tsum = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) {
+        const uint32_t b = (uint32_t)tid * E + e;
+        c[e] = (e < E && b < NB) ? L.cnt[b] : 0u;
+        tsum += c[e];
+    }
+    uint32_t incl = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) L.wsum[wave] = incl;
+    __syncthreads();
+    uint32_t start = incl - tsum;
+    for (int w = 0; w < wave; w++) start += L.wsum[w];
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) {
+        const uint32_t b = (uint32_t)tid * E + e;
+        if (e < E && b < NB) { L.cnt[b] = start; s_start[b] = start; }  // cnt: the bucket's write cursor
+        start += c[e];
+    }
+    if (tid == 0) s_start[NB] = n;
+    __syncthreads();
+    unsigned long long* out = scratch + r0;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const unsigned long long k = seg[i];
+        const uint32_t d = (uint32_t)(k >> 32);
+        out[atomicAdd(&L.cnt[min(NB - 1, (uint32_t)((float)(d - dmin) * inv))], 1u)] = k;
+    }
+    __syncthreads();  // (workgroup-scope visibility of the stores above, like the in-place network's stages)
+    for (uint32_t b = 0; b < NB; b++) {
+        const uint32_t s0 = s_start[b], nb_ = s_start[b + 1] - s0;
+        if (nb_ == 0) continue;
+        uint32_t Nb = 1;
+        while (Nb < nb_) Nb <<= 1;
+        if (nb_ > (uint32_t)BUCKET_CAP_MID) {
+            unsigned long long* sg = out + s0;
+            bitonic_sort_block<false>(sg, nb_, Nb);
+            for (uint32_t q = tid; q < nb_; q += 1024) {
+                const unsigned long long key = sg[q];
+                point_list[r0 + s0 + q] = (uint32_t)key;
+                if (keys_sorted) keys_sorted[r0 + s0 + q] = ((unsigned long long)tile << 32) | (key >> 32);
+            }
+        } else if (Nb <= 4096) bucket_sort_tile<4, 1024, BUCKET_CAP_MID>(L, tile, r0 + s0, nb_, Nb, scratch, point_list, keys_sorted);
+        else bucket_sort_tile<8, 1024, BUCKET_CAP_MID>(L, tile, r0 + s0, nb_, Nb, scratch, point_list, keys_sorted);
+        __syncthreads();  // the LDS image is reused by the next bucket
+    }
+}
+
 __global__ void __launch_bounds__(1024) tile_sort_mid_kernel(int T, int nbl, int seg, uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
-                                                             const unsigned long long* bins,
+                                                             const unsigned long long* bins, unsigned long long* scratch,
                                                              uint32_t* __restrict__ point_list,
-                                                             unsigned long long* __restrict__ keys_sorted)
+                                                             unsigned long long* keys_sorted)
 {
     __shared__ BucketSortLds<BUCKET_CAP_MID, 1024> L;
+    __shared__ uint32_t s_start[BUCKET_CAP_MID + 1];
     for (uint32_t k = blockIdx.x;; k += gridDim.x) {
         uint32_t tile;
         if (!listed_tile(order + GSR_MID_COUNT(T), order + GSR_MID_LIST(T), nbl, seg, k, tile)) break;
@@ -955,15 +1048,7 @@ __global__ void __launch_bounds__(1024) tile_sort_mid_kernel(int T, int nbl, int
         uint32_t N = 1;
         while (N < n) N <<= 1;
         if (n > BUCKET_CAP_MID) {
-            // rare: list longer than the LDS budget -> normalized bitonic network in place in HBM (workgroup-scope visibility
-            // via __syncthreads; the network keeps waves 0-3 busy, the others only join the barriers)
-            unsigned long long* sg = const_cast<unsigned long long*>(bins) + r0;
-            bitonic_sort_block<false>(sg, n, N);
-            for (uint32_t q = threadIdx.x; q < n; q += 1024) {
-                const unsigned long long key = sg[q];
-                point_list[r0 + q] = (uint32_t)key;
-                if (keys_sorted) keys_sorted[r0 + q] = ((unsigned long long)tile << 32) | (key >> 32);
-            }
+            giant_list_sort(L, s_start, tile, r0, n, bins, scratch, point_list, keys_sorted);
         } else if (N <= 4096) bucket_sort_tile<4, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
         else bucket_sort_tile<8, 1024, BUCKET_CAP_MID>(L, tile, r0, n, N, bins, point_list, keys_sorted);
         __syncthreads();  // the LDS image is reused by the next list
@@ -1060,7 +1145,7 @@ void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint3
 
 void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
                                   uint32_t* ranges, const uint32_t* band_count, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list,
-                                  uint64_t* keys_sorted, uint32_t* hint, uint32_t hint_seq, bool launch_mid, hipStream_t s)
+                                  uint64_t* keys_sorted, uint64_t* scratch, uint32_t* hint, uint32_t hint_seq, bool launch_mid, hipStream_t s)
 {
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int T = gx * gy;
@@ -1086,7 +1171,8 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
                        launch_mid ? 0 : 1);
     if (launch_mid)
         hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, nbl, seg, order, ranges,
-                       reinterpret_cast<const unsigned long long*>(bins), point_list, reinterpret_cast<unsigned long long*>(keys_sorted));
+                       reinterpret_cast<const unsigned long long*>(bins), reinterpret_cast<unsigned long long*>(scratch), point_list,
+                       reinterpret_cast<unsigned long long*>(keys_sorted));
 }
 
 int gsr_binning_ablate() { return GSR_BIN_ABLATE; }

@@ -259,7 +259,8 @@ void gsr_launch_tile_binning_head(int P, int W, int H, const float* splat, uint3
                                   uint32_t* band_mem, hipStream_t s);
 void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint32_t* table, uint32_t* totals, uint32_t* order,
                                   uint32_t* ranges, const uint32_t* band_count, uint32_t* band_mem, uint64_t* bins, uint32_t* point_list,
-                                  uint64_t* keys_sorted, uint32_t* hint, uint32_t hint_seq, bool launch_mid, hipStream_t s);
+                                  uint64_t* keys_sorted, uint64_t* scratch /* R keys: lists beyond the LDS budget are partitioned through it (may be keys_sorted) */,
+                                  uint32_t* hint, uint32_t hint_seq, bool launch_mid, hipStream_t s);
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,

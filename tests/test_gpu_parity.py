@@ -122,7 +122,7 @@ def test_long_tile_lists_multiple_batches():
 
 
 def test_very_long_tile_lists_use_the_in_place_sort_path():
-    # > 8192 entries per tile: the per-tile sort leaves LDS and runs in place in HBM; lists of
+    # > 8192 entries per tile: the per-tile sort partitions the list by depth through HBM first (giant_list_sort); lists of
     # 2049..8192 entries take the 1024-thread bucket sort (tile_sort_mid_kernel), 1k..2k the larger 256-thread ones
     st, _ = _fwd_bwd(P=100_000, W=128, H=128, focal=80.0, seed=14, scale_lo=0.004, scale_hi=0.03)
     ln = st["ranges"][:, 1] - st["ranges"][:, 0]
@@ -218,6 +218,26 @@ def test_equal_depths_in_mid_length_lists_overflow_to_the_network():
     assert ((ln > 2048) & (ln <= 8192)).any()
     ctx = hip_forward_raw(g2, cam)
     assert_forward_bit_exact(ctx, st)
+
+
+@pytest.mark.parametrize("distinct,rep,op_scale", [(300, 60, 0.05), (3, 9000, 0.01), (1, 20_000, 0.05)])
+def test_equal_depths_in_lists_beyond_the_lds_budget(distinct, rep, op_scale):
+    """Lists of more than 8192 entries are first partitioned by depth into coarse buckets through the second key array
+    (binning.hip, giant_list_sort), then sorted bucket by bucket.  (300, 60): runs of 60 exact ties overflow the fine buckets of the
+    per-bucket sort (network in LDS); (3, 9000) and (1, 20000): a run of equal depths longer than the LDS budget is a coarse bucket of its
+    own and takes the in-place network in HBM -- ties must still come out in ascending Gaussian index."""
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    g, cam = scene(distinct, 32, 32, 30.0, seed=23, scale_lo=0.3, scale_hi=0.6)
+    idx = torch.randperm(distinct * rep, generator=torch.Generator().manual_seed(4)) % distinct
+    g2 = syn.SyntheticGaussians(g.xyz[idx], g.scales[idx], g.rotations[idx], g.opacities[idx] * op_scale, g.shs[idx])
+    st = oracle_forward(g2, cam)
+    ln = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert (ln > 8192).any(), ln.max()
+    ctx = hip_forward_raw(g2, cam)
+    assert_forward_bit_exact(ctx, st)
+    dL = np.random.default_rng(6).standard_normal((3, 32, 32)).astype(np.float32)
+    check_backward(ctx, st, dL)
 
 
 def test_more_than_16384_tiles_multi_chunk_binning():
