@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step time against the camera's distance: the further away, the fewer tiles the scene covers and the longer their lists (a distant
 dense region seen from a partition's camera).  Lists beyond 8192 entries take the in-place bitonic path of tile_sort_mid_kernel.
-python tools/r4_far_camera.py [P]"""
+python tools/r4_far_camera.py [P] [radius,radius,...] [WxH]"""
 import os
 import sys
 import time
@@ -15,7 +15,8 @@ from based_on_point_cloud_partitions_amd.rasterizer import GaussianRasterization
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
 dev = torch.device("cuda:0")
-W, H, focal = 1920, 1080, 1200.0
+W, H = (int(v) for v in sys.argv[3].split("x")) if len(sys.argv) > 3 else (1920, 1080)
+focal = 1200.0 * W / 1920.0
 g = syn.make_gaussians(P, seed=0)
 xyz, scales, rots, opac, shs = [t.to(dev).requires_grad_(True) for t in (g.xyz, g.scales, g.rotations, g.opacities, g.shs)]
 dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
