@@ -876,7 +876,9 @@ int gsr_debug_export(int P, int64_t R, int W, int H, const void* geom_buffer, co
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)(gx * gy));
         const int bin = gsr_variant("BIN", 1);
         const int in_b = bin ? 0 : gsr_sort_result_in_b(end_bit);
-        if (keys_sorted && bin && im && g)
+        if (keys_sorted && bin && gsr_variant("KEYS", 0))  // the forward wrote the sorted keys itself (GSR_KEYS=1): hand those out
+            hipMemcpyAsync(keys_sorted, b + B.keys_b, (size_t)R * 8, hipMemcpyDeviceToDevice, s);
+        else if (keys_sorted && bin && im && g)
             hipLaunchKernelGGL(export_keys_kernel, dim3(gx * gy), dim3(256), 0, s, (const uint32_t*)(im + I.ranges),
                                (const uint32_t*)(b + B.vals_a), (const float*)(g + G.splat), (unsigned long long*)keys_sorted);
         else if (keys_sorted)

@@ -238,6 +238,13 @@ def test_equal_depths_in_lists_beyond_the_lds_budget(distinct, rep, op_scale):
     assert_forward_bit_exact(ctx, st)
     dL = np.random.default_rng(6).standard_normal((3, 32, 32)).astype(np.float32)
     check_backward(ctx, st, dL)
+    # GSR_KEYS=1: the forward writes the sorted (tile, depth) keys itself -- into the very array the long lists are partitioned through
+    from based_on_point_cloud_partitions_amd import _lib
+    try:
+        _lib.set_variant("KEYS", 1)
+        assert_forward_bit_exact(hip_forward_raw(g2, cam), st)
+    finally:
+        _lib.set_variant("KEYS", 0)
 
 
 def test_more_than_16384_tiles_multi_chunk_binning():
