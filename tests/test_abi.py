@@ -130,3 +130,25 @@ def test_graft_entry_build_runs_and_checks_the_abi_version():
     import __graft_entry__ as g
 
     g.build()
+
+
+def test_rendered_estimate_follows_the_gaussian_count():
+    """The wrapper sizes the binning buffer before the forward from the largest num_rendered seen for (device, P, W, H); after a
+    densification step P is new, and the estimate is the latest entry of the same device and image size scaled by P."""
+    from based_on_point_cloud_partitions_amd import rasterizer as rz
+
+    saved = dict(rz._R_SEEN)
+    try:
+        rz._R_SEEN.clear()
+        assert rz._guess_rendered((0, 1000, 640, 480)) == 0
+        rz._remember_rendered((0, 1000, 640, 480), 8000)
+        rz._remember_rendered((0, 1000, 640, 480), 6000)          # the maximum is kept
+        assert rz._guess_rendered((0, 1000, 640, 480)) == 8000
+        assert rz._guess_rendered((0, 1500, 640, 480)) == 12001   # unseen P: scaled
+        assert rz._guess_rendered((0, 1500, 320, 240)) == 0       # another image size: no basis
+        assert rz._guess_rendered((1, 1500, 640, 480)) == 0       # another device
+        rz._remember_rendered((0, 2000, 640, 480), 30000)
+        assert rz._guess_rendered((0, 4000, 640, 480)) == 60001   # the most recent entry is the basis
+    finally:
+        rz._R_SEEN.clear()
+        rz._R_SEEN.update(saved)
