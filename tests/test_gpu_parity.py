@@ -132,6 +132,15 @@ def test_very_long_tile_lists_use_the_in_place_sort_path():
     assert ((ln > 1024) & (ln <= 4096)).any()
 
 
+def test_tile_lists_of_tens_of_thousands_of_entries():
+    """A distant, dense region behind a handful of tiles: 300,000 Gaussians in a 64 x 64 image -- lists of up to 96,000 entries, walked to
+    the end (n_contrib reaches 88,000): dozens of coarse depth buckets per list in giant_list_sort, hundreds of staging rounds per tile in
+    both blend kernels."""
+    st, _ = _fwd_bwd(P=300_000, W=64, H=64, focal=40.0, seed=5, scale_lo=0.004, scale_hi=0.03)
+    ln = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert ln.max() > 90_000 and (ln > 8192).sum() >= 8 and st["n_contrib"].max() > 80_000
+
+
 def test_lists_beyond_2048_entries_without_the_mid_kernel():
     """The frame-late hint of the tile binning (binning.hip, mid_hint_publish) leaves tile_sort_mid_kernel out when no recent frame
     had a list of more than 2048 entries; a frame that has one after all is sorted by tile_sort_small_kernel's in-place network.
