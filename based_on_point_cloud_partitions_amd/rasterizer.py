@@ -36,15 +36,15 @@ def _remember_rendered(key, rendered):
 
 def _guess_rendered(key):
     """Largest num_rendered seen for (device, P, W, H); for a P not seen yet (the model after a densification step: a new P every
-    hundred iterations, train.py:145-150) the most recent entry of the same device and image size, scaled by the ratio of the Gaussian
-    counts -- so the first frames behind a densification keep the one-call forward instead of re-allocating their way up."""
+    hundred iterations, train.py:145-150) the most recent entry of the same device and image size whose P is within a factor of two,
+    scaled by the ratio of the Gaussian counts -- so the first frames behind a densification keep the one-call forward instead of re-allocating their way up."""
     with _R_SEEN_LOCK:
         r = _R_SEEN.get(key)
         if r is not None:
             return r
         dev, P, W, H = key
         for (d2, P2, W2, H2), r2 in reversed(_R_SEEN.items()):
-            if d2 == dev and W2 == W and H2 == H and P2 > 0:
+            if d2 == dev and W2 == W and H2 == H and P2 > 0 and 2 * P2 >= P >= P2 // 2:  # (a densification step, not another scene)
                 return int(r2 * (P / P2)) + 1
         return 0
 

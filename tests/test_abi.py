@@ -149,6 +149,9 @@ def test_rendered_estimate_follows_the_gaussian_count():
         assert rz._guess_rendered((1, 1500, 640, 480)) == 0       # another device
         rz._remember_rendered((0, 2000, 640, 480), 30000)
         assert rz._guess_rendered((0, 4000, 640, 480)) == 60001   # the most recent entry is the basis
+        assert rz._guess_rendered((0, 4001, 640, 480)) == 0       # more than twice any known P: another scene, no estimate
+        assert rz._guess_rendered((0, 450, 640, 480)) == 0
+        assert rz._guess_rendered((0, 500, 640, 480)) == 4001     # (from the 1000-Gaussian entry: the 2000 one is too far)
     finally:
         rz._R_SEEN.clear()
         rz._R_SEEN.update(saved)
