@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off stress run at the reference's densification ceiling (train.py:146: 6,000,000 Gaussians), 1080p, one camera: full oracle parity
-(forward bit-exact in the default list mode, two-stage gradient check) + step time.  usage (GPU box): python tools/r4_stress_6m.py [P]"""
+(forward bit-exact in the default list mode, two-stage gradient check) + step time.  usage (GPU box): python tools/r4_stress_6m.py [P] [box half-width]"""
 import os
 import sys
 import time
@@ -17,11 +17,14 @@ from based_on_point_cloud_partitions_amd import synthetic as syn  # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 6_000_000
 W, H = 1920, 1080
-g = syn.make_gaussians(P, seed=0, box_min=(-12.0, -12.0, -1.0), box_max=(12.0, 12.0, 1.0))
+HALF = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0  # half-width of the box: 12 = sparse (short lists), 4 = config 2's box (every second list beyond 8192 entries)
+g = syn.make_gaussians(P, seed=0, box_min=(-HALF, -HALF, -1.0), box_max=(HALF, HALF, 1.0))
 cam = syn.ring_cameras(16, W, H, 1200.0)[3]
 t0 = time.time()
 st = oracle_forward(g, cam)
-print(f"oracle forward {time.time() - t0:.1f} s: R = {st['num_rendered']}, visible {int((st['radii'] > 0).sum())}", flush=True)
+ln = st["ranges"][:, 1] - st["ranges"][:, 0]
+print(f"oracle forward {time.time() - t0:.1f} s: R = {st['num_rendered']}, visible {int((st['radii'] > 0).sum())}, tile lists beyond 8192 entries: "
+      f"{int((ln > 8192).sum())} of {ln.size}, longest {int(ln.max())}", flush=True)
 ctx = hip_forward_raw(g, cam)
 assert_forward_bit_exact(ctx, st)
 print("forward bit-exact", flush=True)
