@@ -230,3 +230,19 @@ def test_dedup_matches_numpy_unique_on_adversarial_coordinates():
         assert np.array_equal(got[:, :3], want[:, :3])           # (+0.0 == -0.0 here, as for np.unique)
 
     check()
+
+
+def test_bench_partitions_fill_the_single_gpu_scene_volume():
+    """bench.py --gpus N: a rank's partition (origin box expanded by the reference's 10 % per side) is as large as the N = 1 scene, so the
+    per-GPU work is the same distribution at every N (with 8-wide origin boxes a rank had 15 % fewer instances)."""
+    import bench
+    from based_on_point_cloud_partitions_amd import synthetic as syn
+
+    assert abs(bench.PARTITION_CELL[0] * 1.2 - 8.0) < 1e-9 and abs(bench.PARTITION_CELL[1] * 1.2 - 8.0) < 1e-9
+    for world in (2, 8):
+        for r in range(world):
+            g, centre, box = syn.make_partition(r, world, 4000, seed=0, cell=bench.PARTITION_CELL)
+            lo, hi = g.xyz.min(0).values, g.xyz.max(0).values
+            assert torch.all(hi[:2] - lo[:2] < 8.0 + 1e-4) and torch.all(hi[:2] - lo[:2] > 7.9)
+            assert abs(float(0.5 * (lo[0] + hi[0])) - centre[0]) < 0.05 and abs(float(0.5 * (lo[1] + hi[1])) - centre[1]) < 0.05
+            assert box == syn.partition_origin_box(r, world, cell=bench.PARTITION_CELL)
