@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSR_LIBRARY selects another build of the same library (tools/ab_build.sh + tools/ab_run.sh: A/B variants live in their own directory, the
 # shipped .so is never rebuilt in place); gsr_build_info() says what a loaded binary was built with.
 SO_PATH = os.environ.get("GSR_LIBRARY") or os.path.join(_HERE, "csrc", "libgsrast_mi355x.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _lib = None
 
@@ -29,6 +29,8 @@ PROTOTYPES = {
     "gsr_image_bytes": (c_size, [c_int, c_int]),
     "gsr_binning_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "gsr_backward_scratch_bytes": (c_size, [c_i64, c_int, c_int]),
+    "gsr_gradient_row_limit": (c_i64, []),
+    "gsr_gradient_rows": (c_int, [c_int, c_void_p, c_size, ctypes.POINTER(c_i64), c_void_p]),
     "gsr_forward_geometry": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
                                      c_void_p, c_size, ctypes.POINTER(c_i64), c_void_p]),

@@ -161,6 +161,11 @@ def _plain_conv(conv):
     return isinstance(conv, torch.nn.Conv2d) and conv.bias is not None and conv.padding_mode == "zeros" and conv.weight.dtype == torch.float32
 
 
+def _has_hooks(p):
+    """Tensor hooks or post-accumulate-grad hooks on a parameter: their owners expect the gradient to arrive through autograd."""
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 _SIDE_STREAMS = {}
 
 
@@ -183,7 +188,9 @@ class _Head(torch.autograd.Function):
     everything is ordered on the caller's stream as usual.  Measured at 1080p (tools/r4_head_probe.py): head forward 0.136 ms,
     backward 0.40 ms of which data chain 0.160 and weight gradients 0.188.
     Limit: the weight gradients reach the parameters' `.grad` only (what `loss.backward()` -- train.py:118 -- uses);
-    `torch.autograd.grad(..., inputs=[a head weight])` does not see them.  GSR_APPEARANCE_OVERLAP=0 switches back to plain autograd."""
+    `torch.autograd.grad(..., inputs=[a head weight])`, tensor hooks and AccumulateGrad consumers (a DDP reducer) do not see them:
+    `_head` takes this path only for hook-free leaf weights, and GSR_APPEARANCE_OVERLAP=0 switches back to plain autograd (required
+    when the network is wrapped in DistributedDataParallel; the reference trains every partition's network on its own, train.py:65-73)."""
 
     @staticmethod
     def forward(ctx, x, *params):
@@ -231,7 +238,11 @@ class _Head(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
                     dws[i] = cb(dz, ins[i], ws[i], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-                dz.record_stream(side)
+                # everything the side-stream kernel reads was allocated on the main stream: without these the caching allocator may hand
+                # the saved activations to the next main-stream allocation (the rasterizer backward's scratch) as soon as autograd drops
+                # them, while the weight-gradient kernel is still reading
+                for t in (dz, ins[i], ws[i]):
+                    t.record_stream(side)
                 if i > 0 or ctx.needs_input_grad[0]:
                     gin = cb(dz, ins[i], ws[i], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
                     g = F.pixel_unshuffle(gin, 2).contiguous() if i > 0 else gin
@@ -241,9 +252,12 @@ class _Head(torch.autograd.Function):
 
         def join():
             main.wait_stream(side)
+            cur = torch.cuda.current_stream(dev)  # backward() called under another stream than the forward's: order the adds there too
+            if cur != main:
+                cur.wait_stream(side)
             with torch.no_grad():
                 for w, dw in zip(weights, dws):
-                    dw.record_stream(main)
+                    dw.record_stream(cur)
                     if w.grad is None:
                         w.grad = dw
                     else:
@@ -270,7 +284,7 @@ def _head(net, x):
     overlap = _lib.get_variant("APPEARANCE_OVERLAP", 1) and all(
         tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (1, 1) and tuple(c.dilation) == (1, 1) and
         c.groups == 1 for c in convs) and all(getattr(u.pixel_shuffle, "upscale_factor", None) == 2 for u in ups) and \
-        torch.is_grad_enabled() and all(c.weight.requires_grad and c.weight.is_leaf for c in convs)
+        torch.is_grad_enabled() and all(c.weight.requires_grad and c.weight.is_leaf and not _has_hooks(c.weight) for c in convs)
     if overlap:
         params = []
         for c in convs:

@@ -99,11 +99,14 @@ bool mailbox_acquire(unsigned long long** host_slot, unsigned long long** dev_sl
     return true;
 }
 
-// The long-list hint of this device (two 32-bit words behind the mailbox slots) and this call's frame number.  launch_mid = false only
-// when the hint is there, an earlier frame has reported, and none of the last 2^20 frames had a list of more than 2048 entries (a scene
-// that shows such a list once keeps the kernel for good: the in-kernel fallback costs milliseconds, the empty launch ~2 us).
-uint32_t g_bin_seq = 0;
-bool mid_hint_acquire(uint32_t** hint_dev, uint32_t* seq, bool* launch_mid)
+// The long-list hint of this device (two 32-bit words behind the mailbox slots) and this call's frame number (counted per device: the
+// words are per device).  launch_mid = false only when the hint is there, a frame of THIS problem shape (P, W, H) has reported, none of the
+// last 2^20 frames had a list of more than 2048 entries (a scene that shows such a list once keeps the kernel for good: the in-kernel
+// fallback costs milliseconds, the empty launch ~2 us) and R has not grown by more than a quarter since the kernel was first skipped
+// (densification, a closer camera: longer lists are likely, and the frames the host has already enqueued would all take the fallback).
+struct MidState { uint32_t seq = 0, since = 0, R_ref = 0; int P = -1, W = -1, H = -1; };
+MidState g_mid[kMailDevices];
+bool mid_hint_acquire(int P, int W, int H, uint32_t R, uint32_t** hint_dev, uint32_t* seq, bool* launch_mid)
 {
     *hint_dev = nullptr; *seq = 0; *launch_mid = true;
     int dev = 0;
@@ -113,12 +116,20 @@ bool mid_hint_acquire(uint32_t** hint_dev, uint32_t* seq, bool* launch_mid)
     std::lock_guard<std::mutex> lk(g_mail_mu);
     const Mailbox& m = g_mail[dev];
     if (!m.host) return false;  // (created by the geometry phase's mailbox_acquire)
+    MidState& st = g_mid[dev];
     const volatile uint32_t* h = reinterpret_cast<const volatile uint32_t*>(m.host + kMailSlots);
-    const uint32_t s = ++g_bin_seq;
+    const uint32_t s = ++st.seq;
+    if (P != st.P || W != st.W || H != st.H) { st.P = P; st.W = W; st.H = H; st.since = s; st.R_ref = 0; }
     const uint32_t done = h[0], mid = h[1];
     *hint_dev = reinterpret_cast<uint32_t*>(m.dev + kMailSlots);
     *seq = s;
-    *launch_mid = done == 0u || (mid != 0u && s - mid <= (1u << 20));
+    bool launch = done == 0u || done - st.since > (1u << 31) /* done < since: no frame of this shape has reported */ ||
+                  (mid != 0u && s - mid <= (1u << 20));
+    if (!launch) {
+        if (st.R_ref == 0u) st.R_ref = R;
+        if ((unsigned long long)R * 4ull > (unsigned long long)st.R_ref * 5ull) { launch = true; st.since = s; st.R_ref = 0; }
+    }
+    *launch_mid = launch;
     return true;
 }
 
@@ -238,6 +249,26 @@ size_t gsr_backward_scratch_bytes(int64_t R, int W, int H)
 {
     (void)W; (void)H;
     return gsr_align((size_t)(R > 0 ? R : 1) * GSR_GROW_F * 4);
+}
+
+// The blend backward keeps a gradient-row index in 28 bits beside the 4-bit quadrant mask.  Rows <= instances (only reachable instances
+// own one: ~60 % of R on the benchmark scene), so R below the limit needs no look at the device; above it the row count the forward's
+// offset kernels left in the geometry buffer decides (one 4-byte copy + stream sync, only in that case).
+int64_t gsr_gradient_row_limit(void) { return (int64_t)gsr_variant("ROW_LIMIT", 0x0FFFFFFF); }  // (lowered by tests only)
+int gsr_gradient_rows(int P, const void* geom_buffer, size_t geom_bytes, int64_t* rows_host, void* stream)
+{
+    if (!rows_host) return fail(-1, "rows_host is NULL");
+    *rows_host = 0;
+    if (P <= 0) return 0;
+    const GeomLayout G = gsr_geom_layout(P);
+    if (!geom_buffer || geom_bytes < G.bytes) return fail(-3, "geometry buffer too small");
+    uint32_t rows = 0;
+    const uint32_t* src = (const uint32_t*)((const char*)geom_buffer + G.row_block_offsets) + (P + 255) / 256;
+    hipError_t e = hipMemcpyAsync(&rows, src, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(-4, "gsr_gradient_rows: %s", hipGetErrorString(e));
+    *rows_host = (int64_t)rows;
+    return 0;
 }
 
 // Phase 1 shared by gsr_forward_geometry, gsr_forward and gsr_forward_params: `a` carries the inputs, the outputs inside the
@@ -417,7 +448,7 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
             uint32_t* hint = nullptr;
             uint32_t hint_seq = 0;
             bool launch_mid = true;
-            mid_hint_acquire(&hint, &hint_seq, &launch_mid);
+            mid_hint_acquire(P, W, H, (uint32_t)R, &hint, &hint_seq, &launch_mid);
             StageTimer t(GSR_STAGE_SORT, s, false);
             gsr_launch_tile_binning_tail(P, W, H, (const float*)(g + G.splat), (uint32_t*)(b + B.table), (uint32_t*)(b + B.totals),
                                          (uint32_t*)(b + B.order), ranges, (const uint32_t*)(g + G.band_count), (uint32_t*)(b + B.band), ka, va,
@@ -542,9 +573,19 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
     const GeomLayout G = gsr_geom_layout(P);
     const ImageLayout I = gsr_image_layout(W, H);
     const BinLayout B = gsr_bin_layout((long)R, P, W, H);
-    // render_backward keeps a gradient-row index in 28 bits beside the 4-bit quadrant mask (rows <= instances)
-    if (R >= 0x0FFFFFFF) return fail(-1, "num_rendered out of range (the backward keeps gradient-row indices in 28 bits)");
     if (geom_bytes < G.bytes || image_bytes < I.bytes) return fail(-3, "state buffer too small");
+    // render_backward keeps a gradient-row index in 28 bits beside the 4-bit quadrant mask: the ROW count is what is limited (rows <=
+    // instances; the Python operators make the same check at forward time when a gradient will be asked for)
+    if (R >= gsr_gradient_row_limit()) {
+        int64_t rows = 0;
+        const int rc = gsr_gradient_rows(P, geom_buffer, geom_bytes, &rows, s);
+        if (rc != 0) return rc;
+        if (rows >= gsr_gradient_row_limit()) {
+            snprintf(g_err, sizeof(g_err), "%lld gradient rows: the backward keeps gradient-row indices in 28 bits (limit %lld)",
+                     (long long)rows, (long long)gsr_gradient_row_limit());
+            return -1;
+        }
+    }
     if (R > 0 && (!binning_buffer || binning_bytes < B.bytes)) return fail(-3, "binning buffer too small");
     if (R > 0 && (!scratch || scratch_bytes < gsr_backward_scratch_bytes(R, W, H))) return fail(-3, "backward scratch too small");
     const char* g = (const char*)geom_buffer;

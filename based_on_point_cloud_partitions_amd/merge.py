@@ -68,6 +68,9 @@ def dedup_first_lexicographic(rows):
     sx, sy, sz = ix[order], iy[order], iz[order]
     first = torch.ones(n, dtype=torch.bool, device=rows.device)
     first[1:] = (sx[1:] != sx[:-1]) | (sy[1:] != sy[:-1]) | (sz[1:] != sz[:-1])
+    # a row with a NaN coordinate equals no other row under the float comparison np.unique's field-wise compare makes: never dropped
+    # (the integer keys would merge NaNs of identical bits)
+    first |= torch.isnan(xyz).any(dim=0)[order]
     return rows[order[first]]
 
 

@@ -132,6 +132,22 @@ def rasterize_gaussians_forward(background, means3D, colors, opacity, scales, ro
     return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer
 
 
+def check_gradient_rows(P, rendered, geomBuffer, dev):
+    """The blend backward numbers its gradient rows in 28 bits (include/gsrast_mi355x.h, gsr_gradient_row_limit).  Called by the
+    autograd Functions at FORWARD time when a gradient will be asked for, so that an over-sized frame fails where it was rendered and not
+    inside `loss.backward()`.  Rows <= instances: nothing is read from the device unless num_rendered itself reaches the limit."""
+    lib = _lib.load()
+    limit = int(lib.gsr_gradient_row_limit())
+    if rendered < limit:
+        return
+    rows = ctypes.c_int64(0)
+    with _lib.device_guard(dev):
+        _lib.check(lib.gsr_gradient_rows(int(P), _ptr(geomBuffer), geomBuffer.numel(), ctypes.byref(rows), _stream(dev)), "gsr_gradient_rows")
+    if rows.value >= limit:
+        raise _lib.GsrError(f"{rows.value} gradient rows ({rendered} Gaussian-tile instances): the backward of this rasterizer numbers its "
+                            f"gradient rows in 28 bits (limit {limit}); render without gradients, or split the scene / lower the resolution")
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                  projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer,
                                  imageBuffer, debug):
@@ -225,6 +241,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ex
         else:
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        if any(ctx.needs_input_grad):
+            check_gradient_rows(means3D.size(0), num_rendered, geomBuffer, means3D.device)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,

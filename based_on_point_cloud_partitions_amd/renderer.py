@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from .rasterizer import (NUM_CHANNELS, _guess_rendered, GaussianRasterizationSettings, GaussianRasterizer, _prep, _ptr, _remember_rendered,
-                         _require_hip, _stream)
+                         _require_hip, _stream, check_gradient_rows)
 
 
 def rasterize_gaussian_params_forward(background, xyz, features_dc, features_rest, opacity, scaling, rotation, scale_modifier,
@@ -128,6 +128,8 @@ class _RasterizeGaussianParams(torch.autograd.Function):
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussian_params_forward(
             rs.bg, xyz, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
             rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug)
+        if any(ctx.needs_input_grad):
+            check_gradient_rows(xyz.size(0), num_rendered, geomBuffer, xyz.device)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(xyz, features_dc, features_rest, scaling, rotation, radii, geomBuffer, binningBuffer, imgBuffer)

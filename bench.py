@@ -107,6 +107,36 @@ def stage_bytes(P, V, R, N, key_bits, K=16):
     }
 
 
+def per_rank_report(rows, steps, dominant):
+    """rows[r] = the figures rank r measured itself (see `mine` in main) -> the `per_rank` / `slowest_rank` / `skew_ms` fields of the
+    N > 1 line: which rank set the MAX-over-ranks time, how far apart the ranks left the opening barrier, and whether the slow rank had
+    more work (V, R, listed instances) or just ran slower (the dominant stage's own average)."""
+    keys = ("elapsed_s", "opening_barrier_wait_ms", "t0_wall", "V_mean", "R_mean", "instances_listed_mean", "tile_list_mean",
+            "tile_list_max", "dominant_stage_avg_ms", "render_backward_avg_ms", "ms_per_step_cold", "closing_barrier_wait_ms",
+            "spinup_last_batch_ms_per_step", "device_index")
+    t_first = min(r[2] for r in rows)
+    per = []
+    for i, r in enumerate(rows):
+        d = dict(zip(keys, r))
+        per.append({"rank": i, "device_index": int(d["device_index"]), "ms_per_step": round(1e3 * d["elapsed_s"] / steps, 4),
+                    "it_per_s": round(steps / d["elapsed_s"], 2), "opening_barrier_wait_ms": round(d["opening_barrier_wait_ms"], 3),
+                    "start_offset_ms": round(1e3 * (d["t0_wall"] - t_first), 3), "closing_barrier_wait_ms": round(d["closing_barrier_wait_ms"], 3),
+                    "V_mean": round(d["V_mean"], 1), "R_mean": round(d["R_mean"], 1), "instances_listed_mean": round(d["instances_listed_mean"], 1),
+                    "tile_list_mean": round(d["tile_list_mean"], 1), "tile_list_max": int(d["tile_list_max"]),
+                    "dominant_stage": dominant, "dominant_stage_avg_ms": round(d["dominant_stage_avg_ms"], 4),
+                    "render_backward_avg_ms": round(d["render_backward_avg_ms"], 4), "ms_per_step_cold": round(d["ms_per_step_cold"], 4),
+                    "spinup_last_batch_ms_per_step": round(d["spinup_last_batch_ms_per_step"], 4)})
+    ms = [p_["ms_per_step"] for p_ in per]
+    slow, fast = int(np.argmax(ms)), int(np.argmin(ms))
+    return {"per_rank": per, "slowest_rank": slow, "fastest_rank": fast,
+            "skew_ms": round(max(p_["start_offset_ms"] for p_ in per), 3),  # spread of the ranks' start stamps (one node, one clock)
+            "ms_per_step_spread": round(ms[slow] - ms[fast], 4), "ms_per_step_mean_over_ranks": round(float(np.mean(ms)), 4),
+            "sum_of_rank_rates_it_per_s": round(sum(p_["it_per_s"] for p_ in per), 2),
+            "slowest_vs_fastest": {"ms_per_step": round(ms[slow] / ms[fast], 4),
+                                   "instances_listed": round(per[slow]["instances_listed_mean"] / max(per[fast]["instances_listed_mean"], 1.0), 4),
+                                   "render_backward_avg_ms": round(per[slow]["render_backward_avg_ms"] / max(per[fast]["render_backward_avg_ms"], 1e-9), 4)}}
+
+
 def higher_msb(n):
     msb, step = 16, 16
     while step > 1:
@@ -582,6 +612,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t0_wall = time.time()  # one node: the ranks share this clock, so the spread of these stamps is the skew the opening barrier left
     opening_barrier_ms = 1e3 * (t0 - tb)
     for i in range(args.steps):
         step(args.warmup + i)
@@ -603,10 +634,26 @@ def main():
         stage = _lib.profile_collect()
         if timed.get(dominant, (0.0, 0))[1] > 0:
             stage[dominant] = timed[dominant]  # the dominant stage as measured inside the timed region
+    # Per-rank figures (the reference's launcher reports per partition, auto_train.py:22-51): every rank's own elapsed time, its wait at
+    # the opening barrier, its start stamp, its workload (V / R / listed instances, means over the cameras the timed steps used) and
+    # the dominant stage's average -- all-gathered so that rank 0's line can say WHICH rank set the MAX and why.
+    used_local = [stats[(args.warmup + i) % len(stats)] for i in range(args.steps)]
+    dom_ms, dom_n = (timed.get(dominant) or stage.get(dominant) or (0.0, 0))
+    bwd_ms, bwd_n = (timed.get("render_backward") or stage.get("render_backward") or (0.0, 0))
+    mine = [elapsed, opening_barrier_ms, t0_wall, float(np.mean([u["V"] for u in used_local])), float(np.mean([u["R"] for u in used_local])),
+            float(np.mean([u["listed"] for u in used_local])), float(np.mean([u["tile_mean"] for u in used_local])),
+            float(max(u["tile_max"] for u in used_local)), dom_ms / max(dom_n, 1), bwd_ms / max(bwd_n, 1), cold_ms,
+            1e3 * (elapsed_incl_barrier - elapsed), float(spinup["last_batch_ms_per_step"]) if spinup else 0.0, float(dev.index or 0)]
+    all_ranks = [mine]
     if dist is not None:
-        t = torch.tensor([elapsed, elapsed_incl_barrier], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed, elapsed_incl_barrier], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, elapsed_incl_barrier = (float(v) for v in t.tolist())
+        gathered = torch.zeros(world * len(mine), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(gathered, torch.tensor(mine, dtype=torch.float64, device=cdev))
+        all_ranks = gathered.reshape(world, len(mine)).tolist()
+    per_rank = per_rank_report(all_ranks, args.steps, dominant)
 
     # the same steps over the REFERENCE's tile lists (GSR_CULL=0: sort keys, point_list, ranges, n_contrib bit for bit as the
     # reference builds them; the default lists leave out the instances a splat cannot reach) -- reported beside the headline
@@ -698,7 +745,10 @@ def main():
             avg_ms = ms / n
             kernels.append({"kernel": name, "avg_ms": round(avg_ms, 4), "launches": n,
                             "algorithmic_MB": round(sb[name] / 1e6, 2),
-                            "achieved_GBs": round(sb[name] / 1e9 / (avg_ms * 1e-3), 1)})
+                            # bytes the REFERENCE's data flow moves for this stage / this stage's time: an efficiency against the
+                            # reference's algorithm, not a throughput of this chip (a stage that does the job with fewer bytes reads above
+                            # the 6.29 TB/s copy rate here).  `counted_GBs` below is the throughput: PMC bytes / stage time
+                            "reference_dataflow_GBs": round(sb[name] / 1e9 / (avg_ms * 1e-3), 1), "counted_GBs": None})
         # PMC figures (HBM bytes, VALU instruction counts) come from separate rocprofv3 --pmc passes recorded in
         # profiles/pmc_traffic.json together with the workload and the kernel-source hash they were measured on; they are merged
         # into this run's per-kernel lines only when both match, otherwise they are reported apart under `pmc_from_profile`.
@@ -730,11 +780,13 @@ def main():
                     k["price_list_cycles_per_valu_inst"] = round(pl, 2)
             if "hbm_bytes" in v:
                 k["hbm_traffic_MB"] = round(v["hbm_bytes"] / 1e6, 1)
+                k["counted_GBs"] = round(v["hbm_bytes"] / 1e9 / (k["avg_ms"] * 1e-3), 1)
+                k["counted_frac_of_hbm_peak"] = round(k["counted_GBs"] / HBM_PEAK_GBS, 4)
         kernels.sort(key=lambda k: -k["avg_ms"])
         roofline = None
         if kernels:
             d = kernels[0]
-            hbm = {"achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["achieved_GBs"] / HBM_PEAK_GBS, 4),
+            hbm = {"achieved": d["reference_dataflow_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["reference_dataflow_GBs"] / HBM_PEAK_GBS, 4),
                    "algorithmic_bytes": int(sb[d["kernel"]]), "traffic": pmc.get(d["kernel"], {}).get("hbm_bytes")}
             # `traffic` (and valu_insts) are NOT measured by this run: they are the PMC passes recorded in the profile file below,
             # attached only because its workload and kernel-source hash equal this run's
@@ -804,6 +856,7 @@ def main():
                              "note": "whole distCUDA2 call (min/max, Morton codes, radix sort, gather, box AABBs, search); exact 3-NN: a wave is one "
                                      "64-point box of Morton-sorted queries, scans its own box first, then walks a four-level AABB tree outward "
                                      "(tops, groups, boxes, 16-point quarters) and scans from LDS what its lanes cannot reject (no workgroup barrier)"},
+            **per_rank,
             "rccl_world_size": len(dist_state["ranks_seen"]), "rccl_ranks_seen": dist_state["ranks_seen"],
             "collective_backend": (dist.get_backend() if dist is not None else None), "collective_init_error": dist_state["error"],
             "collective_init": ("before the warm-up (N > 1: the timed region is bracketed by its barriers)" if world > 1 else

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 15
+#define GSR_ABI_VERSION 16
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
@@ -41,6 +41,13 @@ size_t gsr_geometry_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
 size_t gsr_binning_bytes(int64_t R, int P, int W, int H);
 size_t gsr_backward_scratch_bytes(int64_t R, int W, int H);
+/* The one size limit below the reference's (whose 32-bit offsets allow 2^31 instances, rasterizer_impl.cu:280-285): the backward numbers
+ * its gradient rows -- one per (Gaussian, tile) instance the splat can reach, so rows <= num_rendered -- in 28 bits.
+ * gsr_gradient_row_limit() = 2^28 - 1; gsr_gradient_rows reads the row count a finished forward left in its geometry buffer (a 4-byte
+ * copy + stream synchronisation: callers only need it when num_rendered itself is at or above the limit).  The Python operators check at
+ * FORWARD time when a gradient will be asked for; gsr_backward / gsr_backward_params check again and return -1. */
+int64_t gsr_gradient_row_limit(void);
+int gsr_gradient_rows(int P, const void* geom_buffer, size_t geom_bytes, int64_t* rows_host, void* stream);
 
 /* Phase 1 of CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:198-285): frustum cull, covariance
  * projection, SH colour, tiles_touched and its prefix sum.  Writes radii[P] and *num_rendered_host (host
@@ -76,9 +83,9 @@ int gsr_forward(int P, int D, int M, const float* background, const float* means
  * RasterizeGaussiansBackwardCUDA (rasterize_points.cu:151-159): every output element is written.
  * Outputs: dL_dmeans2D[P][3], dL_dcolors[P][3], dL_dopacity[P], dL_dmeans3D[P][3], dL_dcov3D[P][6],
  * dL_dsh[P][M][3], dL_dscales[P][3], dL_drotations[P][4].
- * A reduction from the reference: R (num_rendered) must be below 2^28 - 1 = 268,435,455 instances -- the blend backward keeps a
- * gradient-row index in 28 bits beside a 4-bit quadrant mask -- or the call returns -1 (the reference's 32-bit offsets allow 2^31;
- * BASELINE.json's largest configuration has 1.5e7).  The forward accepts any R below 2^32. */
+ * A reduction from the reference: the number of gradient rows (<= num_rendered; see gsr_gradient_row_limit above) must be below
+ * 2^28 - 1 = 268,435,455 -- the blend backward keeps the row index in 28 bits beside a 4-bit quadrant mask -- or the call returns -1
+ * (BASELINE.json's largest configuration has 1.5e7 instances).  The forward accepts any R below 2^32. */
 int gsr_backward(int P, int D, int M, int64_t R, int W, int H, const float* background, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,

@@ -27,7 +27,7 @@ def pytest_configure(config):
     out = os.path.join(tempfile.mkdtemp(prefix="gsr_rccl_"), "result.json")
     log = open(out + ".log", "w")
     RCCL_CHILD["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_child.py"), out], stdout=log,
-                                          stderr=subprocess.STDOUT)
+                                          stderr=subprocess.STDOUT, start_new_session=True)
     RCCL_CHILD["out"] = out
 
 

@@ -23,7 +23,7 @@ def bench_two_ranks(out):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg1", "--steps", "8", "--warmup", "2",
            "--spinup-ms", "0"]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     out["bench_rc"] = p.returncode
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     out["bench_json_lines"] = len(lines)

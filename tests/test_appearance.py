@@ -231,6 +231,78 @@ def test_decouple_appearance_matches_the_stock_torch_dataflow(overlap):
 
 
 @pytest.mark.gpu
+def test_head_weight_gradients_survive_reuse_of_the_saved_activations():
+    """The head's weight-gradient kernels run on a side stream and read activations allocated on the main stream.  Right after
+    `backward()` autograd drops those tensors; the caching allocator must not hand their blocks to main-stream work that runs beside
+    the side stream (in training: the rasterizer backward's scratch).  Here the main stream allocates and overwrites same-sized
+    blocks immediately, many times over, on a net whose weight gradients are large enough to keep the side stream busy."""
+    from based_on_point_cloud_partitions_amd import _lib
+    from based_on_point_cloud_partitions_amd.appearance import decouple_appearance
+    from based_on_point_cloud_partitions_amd.synthetic import decouple_appearance_torch
+
+    _lib.set_variant("APPEARANCE_OVERLAP", 1)
+    H, W = 544, 960
+    a, b = _model(5), _model(5)
+    img = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    r = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).cuda()
+    tb, _ = decouple_appearance_torch(img.clone().requires_grad_(True), b, 1)
+    (tb * r).sum().backward()
+    want = {n: p.grad.clone() for n, p in b.appearance_network.named_parameters()}
+    for trial in range(3):
+        for p_ in a.appearance_network.parameters():
+            p_.grad = None
+        ta, _ = decouple_appearance(img.clone().requires_grad_(True), a, 1)
+        loss = (ta * r).sum()
+        shapes = [(256, H // 32, W // 32), (64, H // 16, W // 16), (32, H // 8, W // 8), (32, H // 4, W // 4), (16, H // 2, W // 2)]
+        del ta
+        loss.backward()
+        del loss
+        for _ in range(4):  # the freed activations' size classes, poisoned on the main stream at once
+            junk = [torch.full((1,) + s_, float("nan"), device="cuda") for s_ in shapes for _ in range(3)]
+            del junk
+        torch.cuda.synchronize()
+        for n, p_ in a.appearance_network.named_parameters():
+            assert torch.isfinite(p_.grad).all(), (trial, n)
+            assert (p_.grad - want[n]).abs().max().item() <= 2e-4 * max(want[n].abs().max().item(), 1e-6), (trial, n)
+
+
+@pytest.mark.gpu
+def test_head_backward_on_another_stream_and_hooked_weights():
+    """`backward()` under a stream that is not the forward's: the `.grad` accumulation is ordered after the side stream on THAT stream.
+    A weight with a tensor hook takes the plain autograd path (the hook sees the gradient)."""
+    from based_on_point_cloud_partitions_amd import _lib
+    from based_on_point_cloud_partitions_amd.appearance import decouple_appearance
+    from based_on_point_cloud_partitions_amd.synthetic import decouple_appearance_torch
+
+    _lib.set_variant("APPEARANCE_OVERLAP", 1)
+    H, W = 200, 333
+    a, b, c = _model(7), _model(7), _model(7)
+    img = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    r = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).cuda()
+    tb, _ = decouple_appearance_torch(img.clone().requires_grad_(True), b, 2)
+    (tb * r).sum().backward()
+    ta, _ = decouple_appearance(img.clone().requires_grad_(True), a, 2)
+    loss = (ta * r).sum()
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream()
+    with torch.cuda.stream(other):
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in a.appearance_network.named_parameters()}  # read on the backward's stream, no device sync
+    other.synchronize()
+    close = lambda u, v: (u - v).abs().max().item() <= 2e-4 * max(v.abs().max().item(), 1e-6)
+    for n, p in b.appearance_network.named_parameters():
+        assert close(grads[n], p.grad), n
+    seen = []
+    c.appearance_network.conv1.weight.register_hook(lambda g: seen.append(g.clone()))
+    tc, _ = decouple_appearance(img.clone().requires_grad_(True), c, 2)
+    (tc * r).sum().backward()
+    torch.cuda.synchronize()
+    assert len(seen) == 1 and close(seen[0], b.appearance_network.conv1.weight.grad)
+    for (n, pc), (_, pb) in zip(c.appearance_network.named_parameters(), b.appearance_network.named_parameters()):
+        assert close(pc.grad, pb.grad), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,H,W", [(256, 33, 60), (32, 264, 480), (5, 1, 1), (64, 7, 130)])
 def test_fused_bias_relu_matches_torch(C, H, W):
     from based_on_point_cloud_partitions_amd.appearance import _BiasReLU

@@ -2,7 +2,7 @@
 
 Bars (BASELINE.json north_star / BASELINE.md §5): bit-exact radii, tiles_touched, depth bits, sort keys,
 point_list, ranges, n_contrib -- and, because oracle and kernels share one arithmetic contract, also bit-exact
-final_T and out_color; gradients element-wise within 1e-4 + 1e-4 |want| + 4e-6 x the element's computed condition number
+final_T and out_color; gradients element-wise within 1e-4 + 1e-4 |want| + 1e-6 x the element's computed condition number
 (tests/helpers.py; the reference itself sums them with order-dependent float atomics).
 """
 import os
@@ -33,8 +33,10 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _fwd_bwd(P, W, H, focal, seed=0, bg=(0.0, 0.0, 0.0), deg=3, scale_lo=0.004, scale_hi=0.04, cam_index=0, n_cams=4,
-             colors=False, cov=False, scale_modifier=1.0, backward=True):
+             colors=False, cov=False, scale_modifier=1.0, backward=True, M=None):
     g, cam = scene(P, W, H, focal, seed=seed, scale_lo=scale_lo, scale_hi=scale_hi, cam_index=cam_index, n_cams=n_cams)
+    if M is not None:  # sh handed over as [P, M, 3] with M < 16 coefficients per Gaussian (rasterize_points.cu:83-86: M = sh.size(1))
+        g = g._replace(shs=g.shs[:, :M].contiguous())
     rng = np.random.default_rng(seed + 100)
     cp = rng.uniform(0, 1, (P, 3)).astype(np.float32) if colors else None
     cv = None
@@ -98,6 +100,25 @@ def test_snapshot_scene_against_committed_golden():
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
 def test_small_scene_all_sh_degrees(deg):
     _fwd_bwd(P=3000, W=160, H=128, focal=100.0, seed=deg, bg=(0.3, 0.5, 0.7), deg=deg, scale_lo=0.01, scale_hi=0.15)
+
+
+@pytest.mark.parametrize("deg,M", [(0, 1), (1, 4), (2, 9), (1, 16), (0, 4), (2, 16)])
+def test_fewer_than_16_sh_coefficients_through_the_standard_operator(deg, M):
+    """A model trained with --sh_degree 1 hands the rasterizer sh of shape [P,4,3]: the reference strides by M = sh.size(1)
+    (rasterize_points.cu:83-86,145-148; forward.cu:29) and evaluates `deg` <= the degree M allows.  gsr_forward / gsr_backward with
+    that layout: forward bit-exact, two-stage gradients, dL_dsh of shape [P,M,3] with the coefficients above `deg` left zero."""
+    st, ctx = _fwd_bwd(P=3000, W=160, H=128, focal=100.0, seed=20 + deg, bg=(0.3, 0.5, 0.7), deg=deg, scale_lo=0.01, scale_hi=0.15, M=M)
+    assert st["M"] == M and tuple(ctx["sh"].shape) == (3000, M, 3)
+    dL = np.random.default_rng(4).standard_normal((3, 128, 160)).astype(np.float32)
+    got = hip_backward_raw(ctx, dL)
+    assert got["dL_dsh"].shape == (3000, M, 3)
+    assert not got["dL_dsh"][:, (deg + 1) ** 2:].any()
+    assert got["dL_dsh"][:, :(deg + 1) ** 2].any()
+
+
+def test_fewer_than_16_sh_coefficients_mid_size():
+    """[P,4,3] at a size where every workgroup of the per-Gaussian kernels is full (50k Gaussians, 640x360)."""
+    _fwd_bwd(P=50_000, W=640, H=360, focal=400.0, seed=31, deg=1, M=4)
 
 
 def test_config1_10k_256(request):
@@ -591,6 +612,51 @@ def test_prefiltered_raises_where_the_reference_traps():
     torch.cuda.synchronize()
     img3, radii3 = GaussianRasterizer(pre)(**args)           # and the library is fine afterwards
     assert torch.equal(img3, img0) and torch.equal(radii3, radii0)
+
+
+def test_gradient_row_limit_is_checked_at_forward_time_and_on_rows():
+    """The backward numbers gradient rows in 28 bits (the reference's 32-bit offsets allow 2^31 instances, rasterizer_impl.cu:280-285).
+    With the limit lowered (GSR_ROW_LIMIT, tests only): a frame whose ROW count is below it passes although num_rendered is above; a
+    frame with too many rows raises in the FORWARD when a gradient will be asked for, renders fine without gradients, and gsr_backward
+    itself refuses it."""
+    from based_on_point_cloud_partitions_amd import GaussianRasterizer, _lib
+
+    P, W, H = 3000, 160, 120
+    g, cam = scene(P, W, H, 100.0, seed=12, scale_lo=0.01, scale_hi=0.08)
+    dev = "cuda"
+    lib = _lib.load()
+    assert lib.gsr_gradient_row_limit() == 2 ** 28 - 1
+    ctx = hip_forward_raw(g, cam)
+    import ctypes
+    rows = ctypes.c_int64(0)
+    assert lib.gsr_gradient_rows(P, ctx["gb"].data_ptr(), ctx["gb"].numel(), ctypes.byref(rows), None) == 0
+    R, rows = ctx["R"], rows.value
+    listed = int((ctx["ex"]["ranges"][:, 1] - ctx["ex"]["ranges"][:, 0]).sum())
+    assert 0 < rows <= R and (rows == listed or reference_lists_on())  # one row per reachable instance
+    args = lambda grad: dict(means3D=g.xyz.to(dev).requires_grad_(grad), means2D=torch.zeros(P, 3, device=dev), opacities=g.opacities.to(dev),
+                             shs=g.shs.to(dev), scales=g.scales.to(dev), rotations=g.rotations.to(dev))
+    rz = GaussianRasterizer(hip_settings(cam, (0.0, 0.0, 0.0), 3, device=dev))
+    try:
+        if rows < R:
+            _lib.set_variant("ROW_LIMIT", rows + 1)      # num_rendered above the limit, rows below: fine
+            img, _ = rz(**args(True))
+            img.sum().backward()
+        _lib.set_variant("ROW_LIMIT", rows)              # rows at the limit
+        with pytest.raises(_lib.GsrError, match="gradient rows"):
+            rz(**args(True))
+        img, _ = rz(**args(False))                       # no gradient asked for: the forward accepts any R
+        assert torch.equal(img, ctx["color"])
+        with pytest.raises(_lib.GsrError, match="gradient rows"):
+            hip_backward_raw(ctx, np.zeros((3, H, W), np.float32))
+    finally:
+        _lib.set_variant("ROW_LIMIT", 2 ** 28 - 1)
+    rz(**args(True))[0].sum().backward()
+
+
+def reference_lists_on():
+    from helpers import reference_lists
+
+    return reference_lists()
 
 
 def test_non_finite_inputs_are_memory_safe(tile_list_mode):

@@ -232,6 +232,41 @@ def test_dedup_matches_numpy_unique_on_adversarial_coordinates():
     check()
 
 
+def test_dedup_keeps_every_row_with_a_nan_coordinate():
+    """np.unique(axis=0) compares fields as floats, so a row with a NaN coordinate equals no other and every one survives
+    (scene/ptgs/merge_partitions.py:152-158); the integer-key sort must not merge NaNs of identical bits.  The rows without NaN
+    are deduplicated exactly as before."""
+    nan = float("nan")
+    pts = np.array([[nan, 1, 2], [0, 1, 2], [nan, 1, 2], [0, 1, 2], [1, nan, 0], [1, nan, 0], [3, 3, nan], [-1, 0, 0]], np.float32)
+    rows = np.random.default_rng(0).standard_normal((len(pts), merge.ROW)).astype(np.float32)
+    rows[:, :3] = pts
+    got = merge.dedup_first_lexicographic(torch.from_numpy(rows.copy())).numpy()
+    _, idx = np.unique(pts, axis=0, return_index=True)
+    assert got.shape[0] == len(idx) == 7
+    has_nan = np.isnan(got[:, :3]).any(axis=1)
+    assert has_nan.sum() == 5
+    assert sorted(got[has_nan][:, 3].tolist()) == sorted(rows[np.isnan(pts).any(axis=1)][:, 3].tolist())
+    clean = rows[~np.isnan(pts).any(axis=1)]
+    _, ci = np.unique(clean[:, :3], axis=0, return_index=True)
+    assert np.array_equal(got[~has_nan], clean[ci])
+
+
+def test_bench_per_rank_report_names_the_slowest_rank():
+    """The N > 1 bench line carries every rank's own figures (the reference's launcher reports per partition, auto_train.py:22-51):
+    from the all-gathered rows rank 0 derives who set the MAX, the start skew and whether that rank had more work."""
+    import bench
+
+    rows = [[0.0200, 0.10, 100.0000, 5e5, 3.70e6, 2.30e6, 450, 2000, 0.32, 0.32, 0.70, 0.05, 0.69, 0],
+            [0.0230, 0.30, 100.0004, 5e5, 3.90e6, 2.50e6, 470, 2100, 0.36, 0.36, 0.75, 0.01, 0.70, 1],
+            [0.0190, 0.00, 100.0001, 5e5, 3.60e6, 2.20e6, 440, 1900, 0.31, 0.31, 0.69, 0.09, 0.68, 2]]
+    r = bench.per_rank_report(rows, 20, "render_backward")
+    assert r["slowest_rank"] == 1 and r["fastest_rank"] == 2 and abs(r["skew_ms"] - 0.4) < 1e-6
+    assert [p["rank"] for p in r["per_rank"]] == [0, 1, 2] and r["per_rank"][1]["ms_per_step"] == 1.15
+    assert r["per_rank"][2]["start_offset_ms"] == 0.1 and r["per_rank"][0]["start_offset_ms"] == 0.0
+    assert abs(r["slowest_vs_fastest"]["instances_listed"] - 2.5 / 2.2) < 1e-3
+    assert abs(r["sum_of_rank_rates_it_per_s"] - (1000.0 + 20 / 0.023 + 20 / 0.019)) < 0.05
+
+
 def test_bench_partitions_fill_the_single_gpu_scene_volume():
     """bench.py --gpus N: a rank's partition (origin box expanded by the reference's 10 % per side) is as large as the N = 1 scene, so the
     per-GPU work is the same distribution at every N (with 8-wide origin boxes a rank had 15 % fewer instances)."""

@@ -1,5 +1,6 @@
-"""BASELINE.json configs[2] and configs[4] on ONE GPU: the eight partition workloads that `bench.py --gpus 8` gives its ranks
-(cfg3: independent sub-scenes, auto_train.py:22-51) through the HIP path against the oracle, and the seamless merge + evaluation of
+"""BASELINE.json configs[2] and configs[4] on ONE GPU: the eight partition workloads that `bench.py --gpus 8` gives its ranks -- built
+with the bench's own origin-box size, `bench.PARTITION_CELL`, so these ARE the scenes the scaling run times (cfg3: independent
+sub-scenes, auto_train.py:22-51) -- through the HIP path against the oracle, and the seamless merge + evaluation of
 cfg5 (scene/ptgs/merge_partitions.py:95-170, metrics.py:41-113) on device tensors against the reference's numpy sequence.
 The collective itself is covered by the world_size-2 gloo tests (tests/test_merge_gloo.py); here world_size is 1 and the eight
 partitions are processed one after the other.
@@ -8,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+import bench
 from helpers import assert_forward_bit_exact, check_backward, hip_forward_raw, oracle_forward
 
 pytestmark = pytest.mark.gpu
@@ -20,19 +22,20 @@ def _boxes():
 
     out = []
     for r in range(WORLD):
-        x0, x1, y0, y1 = syn.partition_origin_box(r, WORLD)
+        x0, x1, y0, y1 = syn.partition_origin_box(r, WORLD, cell=bench.PARTITION_CELL)
         out.append((x0, y0, x1, y1))
     return out
 
 
 @pytest.mark.parametrize("rank", range(WORLD))
 def test_cfg3_partition_workload_full_parity(rank):
-    """Partition `rank` of 8 (boxes shifted to x in [-4, 28], y in [-4, 12]: other fp magnitudes than cfg2's origin-centred box),
+    """Partition `rank` of 8 as `bench.py --gpus 8` builds it (origin boxes of 6.67 x 6.67 in a 4 x 2 grid from (-4, -4): other fp
+    magnitudes than cfg2's origin-centred box; expanded by 10 % per side each holds the N = 1 scene's 8 x 8 volume),
     500k Gaussians, 1080p, one camera of its ring: forward bit-exact in both tile-list modes, gradients at the element-wise bar."""
     from based_on_point_cloud_partitions_amd import _lib
     from based_on_point_cloud_partitions_amd import synthetic as syn
 
-    g, centre, _box = syn.make_partition(rank, WORLD, P, seed=0)
+    g, centre, _box = syn.make_partition(rank, WORLD, P, seed=0, cell=bench.PARTITION_CELL)
     cam = syn.ring_cameras(16, W, H, FOCAL, center=centre)[(5 * rank + 1) % 16]
     st = oracle_forward(g, cam)
     assert st["num_rendered"] > 2_000_000
@@ -55,7 +58,7 @@ def _partition_blocks(n_per_rank, device):
 
     blocks = []
     for r in range(WORLD):
-        g, _c, _b = syn.make_partition(r, WORLD, n_per_rank, seed=0)
+        g, _c, _b = syn.make_partition(r, WORLD, n_per_rank, seed=0, cell=bench.PARTITION_CELL)
         raw_op = torch.logit(g.opacities.clamp(1e-4, 1 - 1e-4))
         blk = merge.pack_block(g.xyz, g.shs[:, :1], g.shs[:, 1:], raw_op, torch.log(g.scales), g.rotations)
         if r > 0:  # rows whose xyz an earlier partition already holds: np.unique keeps the FIRST occurrence

@@ -13,17 +13,36 @@ from conftest import RCCL_CHILD
 
 pytestmark = pytest.mark.gpu
 
+CHILD_WAIT_S = 420
+
+
+def _log_tail(out):
+    try:
+        return open(out + ".log").read()[-4000:]
+    except OSError as e:
+        return f"(no log: {e})"
+
 
 @pytest.fixture(scope="module")
 def report():
     p, out = RCCL_CHILD["proc"], RCCL_CHILD["out"]
     if p is None:
         pytest.skip("child not started (run with -m gpu on a GPU box)")
+    # the child has been running since pytest_configure (beside the first tests); it needs about a minute.  Well inside the driver's
+    # 900 s limit for the whole GPU suite a hung child becomes a FAILING TEST with its log, not a killed run
     t0 = time.time()
-    while p.poll() is None and time.time() - t0 < 1100:
+    while p.poll() is None and time.time() - t0 < CHILD_WAIT_S:
         time.sleep(1.0)
-    assert p.poll() is not None, "tests/rccl_child.py did not finish"
-    assert os.path.exists(out), open(out + ".log").read()[-4000:]
+    if p.poll() is None:
+        import signal
+
+        try:
+            os.killpg(p.pid, signal.SIGKILL)  # the child leads its own process group (conftest: start_new_session), ranks included
+        except OSError:
+            p.kill()
+        p.wait(timeout=30)
+        pytest.fail(f"tests/rccl_child.py still running after {CHILD_WAIT_S} s; killed.  Its log:\n" + _log_tail(out))
+    assert os.path.exists(out), _log_tail(out)
     return json.load(open(out))
 
 
@@ -45,3 +64,11 @@ def test_bench_starts_its_own_ranks(report):
     assert b["collective_backend"] in ("gloo", "nccl")  # gloo when two ranks share the box's single GPU
     assert b["merge"]["world_size"] == 2 and len(b["merge"]["rows_per_rank_after_crop"]) == 2
     assert b["scaling"] == "weak" and b["value"] > 0
+    # the line explains its own MAX-over-ranks time: per-rank elapsed / barrier waits / workload / dominant stage, who was slowest
+    pr = b["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and b["slowest_rank"] in (0, 1) and b["fastest_rank"] in (0, 1) and b["skew_ms"] >= 0.0
+    for p in pr:
+        assert p["ms_per_step"] > 0 and p["V_mean"] > 0 and p["R_mean"] > 0 and p["instances_listed_mean"] > 0
+        assert p["render_backward_avg_ms"] > 0 and p["opening_barrier_wait_ms"] >= 0 and p["start_offset_ms"] >= 0
+    assert abs(max(p["ms_per_step"] for p in pr) - b["ms_per_step"]) < 1e-3  # the headline IS the slowest rank's time
+    assert pr[0]["R_mean"] != pr[1]["R_mean"]  # two different partitions
