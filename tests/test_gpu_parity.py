@@ -531,18 +531,6 @@ def test_debug_mode_snapshots_and_synchronises(tmp_path, monkeypatch):
     assert len(snap) == 21 and torch.equal(snap[12], dL.cpu()) and snap[20] is True
 
 
-def test_backward_refuses_more_instances_than_its_row_index_holds():
-    """render_backward keeps the gradient-row index of a staged entry in 28 bits (the other 4 hold its quadrant mask): 2^28 - 1
-    instances and more are refused by the C ABI before anything is launched."""
-    from based_on_point_cloud_partitions_amd import GsrError
-
-    g, cam = scene(500, 64, 48, 50.0, seed=3)
-    ctx = dict(hip_forward_raw(g, cam))
-    ctx["R"] = 0x0FFFFFFF
-    with pytest.raises(GsrError, match="28 bits"):
-        hip_backward_raw(ctx, np.zeros((3, 48, 64), np.float32))
-
-
 def test_extreme_needles_clipped_at_the_image_border():
     """200:1 ... 500:1 needles, far longer than the image, at every orientation: their tile rectangle is the whole 8 x 8-tile image
     (<= 64 tiles, so the reach mask decides which instances are listed), and the conic is so ill-conditioned (cx cz / det up to
