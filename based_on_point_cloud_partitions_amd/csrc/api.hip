@@ -225,6 +225,9 @@ static bool gsr_variant_store(const char* name, int value)
 // those instances lie outside the alpha >= 1/255 ellipse (gsr_reach_mask) and cannot contribute to any pixel.  Leaving them out
 // changes no pixel and no gradient; GSR_CULL=0 keeps the reference's lists bit for bit (sort keys, point_list, ranges, n_contrib).
 bool gsr_cull_enabled() { return gsr_variant("CULL", 1) && gsr_variant("BIN", 1); }
+// The blend log (render_forward.hip) is written by the quadrant walk of the forward only; forward and backward of one frame must see the
+// same answer (the switches are read at launch time: change them between frames, not between a forward and its backward).
+bool gsr_blend_log_enabled() { return gsr_variant("BLEND_LOG", 1) && gsr_variant("QUAD", 1) == 1 && gsr_variant("WAVE8X8", 1) != 0; }
 
 extern "C" {
 
@@ -481,8 +484,9 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
     {
         StageTimer t(GSR_STAGE_RENDER_FWD, s);
         const uint32_t* order = (R > 0 && gsr_variant("BIN", 1)) ? (const uint32_t*)(b + B.order) : nullptr;
+        unsigned long long* blend_log = (R > 0 && gsr_blend_log_enabled()) ? (unsigned long long*)(b + B.blend_log) : nullptr;
         gsr_launch_render_forward(W, H, ranges, point_list, (const float*)(g + G.splat), background, (float*)(im + I.final_T),
-                                  (uint32_t*)(im + I.n_contrib), out_color, order, s);
+                                  (uint32_t*)(im + I.n_contrib), out_color, order, blend_log, s);
     }
     return check_hip("forward_render");
 }
@@ -600,7 +604,8 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
         gsr_launch_render_backward(W, H, (const uint32_t*)(im + I.ranges), point_list, (const float*)(g + G.splat), background,
                                    (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
                                    gsr_variant("BIN", 1) ? (const uint32_t*)(b + B.order) : nullptr, (float*)scratch,
-                                   (float)R / (float)(gx * gy), s);
+                                   (float)R / (float)(gx * gy),
+                                   gsr_blend_log_enabled() ? (const unsigned long long*)(b + B.blend_log) : nullptr, s);
     }
     a.cov3D_in = cov3D_precomp ? cov3D_precomp : (const float*)(g + G.cov3D);
     a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);

@@ -52,7 +52,7 @@ struct ImageLayout {
 #define GSR_CLASS_HIST(T) (3 * (T) + 2 * GSR_BAND_COUNTERS)
 
 struct BinLayout {
-    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, band, fixed_bytes, bytes;
+    size_t keys_a, keys_b, vals_a, vals_b, hist_global, hist_blocks, table, totals, order, band, blend_log, fixed_bytes, bytes;
     uint32_t sort_blocks;
 };
 
@@ -193,8 +193,19 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
     L.vals_a = o; o = gsr_align(o + r * 4);
     L.vals_b = o; o = gsr_align(o + r * 4);
     L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
+    {   // blend log (render_forward.hip -> render_backward.hip): four 64-bit lane masks per list position, one spare position per tile
+        const size_t t = (size_t)((W + GSR_TILE_X - 1) / GSR_TILE_X) * ((H + GSR_TILE_Y - 1) / GSR_TILE_Y);
+        L.blend_log = o; o = gsr_align(o + (r + t + 1) * 32);
+    }
     L.bytes = o;
     return L;
+}
+
+// Blend log: index (in 64-bit words) of the mask of (tile, list position r0 + k = first position of the tile + k, quadrant q); position
+// `list length` of a tile is its spare slot (written by the padding entries of the forward's unrolled walk, never read).
+__host__ __device__ __forceinline__ size_t gsr_blend_log_slot(uint32_t r0, uint32_t tile, uint32_t q)
+{
+    return ((size_t)r0 + (size_t)tile) * 4 + q;
 }
 
 // rasterizer_impl.cu:35-50 (number of key bits that hold the tile id)
@@ -264,10 +275,12 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
-                               hipStream_t s);
+                               unsigned long long* blend_log, hipStream_t s);
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                                const uint32_t* order, float* grad_rows, float mean_list, hipStream_t s);
+                                const uint32_t* order, float* grad_rows, float mean_list, const unsigned long long* blend_log,
+                                hipStream_t s);
+bool gsr_blend_log_enabled();                 // the forward's quadrant walk logs its blend decisions for the backward (render_forward.hip)
 int gsr_variant(const char* name, int dflt);  // experiment switch read from the environment (GSR_<name>)
 bool gsr_cull_enabled();                      // tile lists without the instances the splat's alpha >= 1/255 ellipse cannot reach
 struct GaussBackwardArgs {

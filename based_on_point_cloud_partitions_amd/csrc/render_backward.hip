@@ -430,13 +430,295 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
     }
 }
 
+
+// ---- the log walk (round 5) ----------------------------------------------------------------------------------------------------------
+// The same kernel fed with the forward's blend log (render_forward.hip): for every (list entry, quadrant) visit the forward made, the
+// 64-bit mask of the pixels that blended the entry.  Everything render_backward_kernel re-derives per visit -- is the entry in front of
+// the pixel's last contributor (n_contrib), does power pass the threshold, is power <= 0, is alpha >= 1/255 (with an exact second exp when
+// the fast one lands near the threshold) -- is ONE scalar load here, and the set of blended pairs is the forward's by construction.
+// Why it pays (tools/smem_probe.hip, profiles/README.md round 5): a SALU instruction costs 1.74 ns per SIMD on gfx950 -- more than a
+// plain VALU instruction (1.1 ns) -- and the decision chains were ~27 scalar instructions per visit (ballot, s_and, s_cmp, s_cbranch, four
+// times over) beside ~10 of the visit's 44 VALU issue slots; both pipes of the old kernel ran at 75-90 %.
+// The walk still needs the splat's reach bit per quadrant (a slot the forward did not visit holds garbage) and the quadrant's last
+// contributor (slots behind the forward wave's exit were never written): both are applied by the staging threads (gsr_quad_mask,
+// k < max n_contrib of the quadrant), so a staged bit means "the forward wrote this slot".
+template <int NQ>
+__global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE ? GSR_BWD_WPE : 8)))
+render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ranges,
+                           const uint32_t* __restrict__ point_list, const float* __restrict__ splat, const float* __restrict__ bg,
+                           const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                           const float* __restrict__ dL_dpixels, const unsigned long long* __restrict__ blend_log,
+                           float* __restrict__ grad_rows)
+{
+    constexpr int WPT = 4 / NQ;      // waves per tile
+    constexpr int NT = 64 * WPT;     // threads
+    constexpr int BATCH = NQ == 1 ? GSR_BWD_BATCH1 : 128;  // list entries staged per round
+    constexpr int SW = BATCH / 64;                          // staging waves
+    __shared__ float4 s_a[BATCH];    // mx, my, conic.x, conic.y
+    __shared__ float4 s_b[BATCH];    // conic.z, opacity, -, r
+    __shared__ float2 s_c[BATCH];    // g, b
+    __shared__ uint32_t s_row[BATCH];  // gradient row index | (quadrants whose log slot the forward wrote) << 28
+    constexpr int NACC = NQ == 2 ? 1 : 2;
+    __shared__ float s_acc[NACC * BATCH * NV];
+    uint32_t* s_hi = reinterpret_cast<uint32_t*>(s_acc);  // [4]: largest n_contrib of each quadrant, only before the first round
+
+    const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;
+    const uint32_t bx = tile % (uint32_t)gx, by = tile / (uint32_t)gx;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(ranges[2 * tile]);
+    const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
+    const uint32_t total = r1 - r0;
+    if (total == 0) return;
+
+    const uint32_t lx = lane & 7, ly = lane >> 3;
+    const int q_first = wave * NQ;
+    const float tile_x0 = (float)(bx * GSR_TILE_X), tile_y0 = (float)(by * GSR_TILE_Y);
+    const float pxf0 = tile_x0 + (float)(8 * (q_first & 1)) + (float)lx, pxf1 = pxf0 + 8.0f;  // NQ = 2: x halves 0 and 1
+    const float pyf = tile_y0 + (float)(8 * (q_first >> 1)) + (float)ly;
+    const size_t plane = (size_t)H * W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    float T[NQ], tfbg[NQ], behind[NQ], dL0[NQ], dL1[NQ], dL2[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint32_t px = bx * GSR_TILE_X + (uint32_t)(8 * ((q_first + q) & 1)) + lx;
+        const uint32_t py = by * GSR_TILE_Y + (uint32_t)(8 * ((q_first + q) >> 1)) + ly;
+        const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+        const size_t pix_id = (size_t)W * py + px;
+        const float Tf = inside ? final_Ts[pix_id] : 0.f;
+        T[q] = Tf;
+        uint32_t m = inside ? n_contrib[pix_id] : 0u;
+        dL0[q] = dL1[q] = dL2[q] = 0.f;
+        if (inside) { dL0[q] = dL_dpixels[pix_id]; dL1[q] = dL_dpixels[plane + pix_id]; dL2[q] = dL_dpixels[2 * plane + pix_id]; }
+        tfbg[q] = Tf * (((0.f + bg0 * dL0[q]) + bg1 * dL1[q]) + bg2 * dL2[q]);  // T_final * (bg . dL/dpixel), backward.cu:526-530
+        behind[q] = 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+        if (lane == 0) s_hi[q_first + q] = m;  // the quadrant's last contributor: the forward wave walked at least this far
+    }
+    __syncthreads();
+    const uint32_t h0 = __builtin_amdgcn_readfirstlane(s_hi[0]), h1 = __builtin_amdgcn_readfirstlane(s_hi[1]);
+    const uint32_t h2 = __builtin_amdgcn_readfirstlane(s_hi[2]), h3 = __builtin_amdgcn_readfirstlane(s_hi[3]);
+    const uint32_t hi = max(max(h0, h1), max(h2, h3));  // number of list entries that matter to any pixel of the tile
+
+    unsigned long long M0 = 0xAAAAAAAAAAAAAAAAull, M2 = 0x0004000400040004ull;
+    asm volatile("" : "+s"(M0), "+s"(M2));  // kept as two register PAIRS (the halves are equal: the compiler would rebuild the pair per use)
+    const bool writer = gsr_sum9_writer(lane);
+    const int my_slot = gsr_sum9_slot(lane);
+    float* my_acc = s_acc + (NQ == 2 ? 0 : (wave >> 1) * BATCH * NV);
+    const int rounds = (int)((hi + BATCH - 1) / BATCH);
+    // the masks of (list position 0 of the tile, this wave's first quadrant); position k lies 4 k words further
+    const unsigned long long* logw = blend_log + gsr_blend_log_slot(r0, tile, (uint32_t)q_first);
+
+    for (int i = 0; i < rounds; i++) {
+        // ---- stage this batch (back to front): as render_backward_kernel, plus: a quadrant bit is kept only for k < the quadrant's last
+        // contributor ----
+        const uint32_t progress = (uint32_t)i * BATCH + tid;
+        uint32_t qm = 0, row = GSR_NO_ROW;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (tid < BATCH && progress < hi) {
+            const uint32_t k = hi - 1 - progress;
+            const uint32_t id = point_list[r0 + k];
+            const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+            const float4 q3 = rec[3];
+            uint32_t mnx, mny, mxx, mxy;
+            gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
+            const uint32_t tilepos = (by - mny) * (mxx - mnx) + (bx - mnx);
+            bool keep;
+            if (__float_as_uint(q3.w) == 0u) {
+                const unsigned long long mask = ((unsigned long long)__float_as_uint(q3.z) << 32) | __float_as_uint(q3.y);
+                keep = (mask >> tilepos) & 1ull;
+                row = __float_as_uint(q3.x) + (uint32_t)__popcll(mask & ((1ull << tilepos) - 1ull));
+            } else {
+                const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
+                row = __float_as_uint(q3.x) + tilepos;
+                keep = !gsr_tile_cannot_touch(q0.x, q0.y, q0.z, q0.w, q1.x, pthr, tile_x0, tile_y0);
+                if (!keep) {
+                    const float z[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    gsr_row_store(grad_rows, row, z);
+                }
+            }
+            if (keep) {
+                qm = gsr_quad_mask(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0);
+                qm &= (k < h0 ? 1u : 0u) | (k < h1 ? 2u : 0u) | (k < h2 ? 4u : 0u) | (k < h3 ? 8u : 0u);
+            }
+            if (!keep) row = GSR_NO_ROW;
+        }
+        __syncthreads();  // previous batch flushed
+        if (tid < BATCH) {
+            s_a[tid] = q0;
+            s_b[tid] = make_float4(q1.x, q1.y, 0.f, q1.z);
+            s_c[tid] = make_float2(q1.w, q2.x);
+            s_row[tid] = row | (qm << 28);
+#pragma unroll
+            for (int t = 0; t < NACC * NV; t++) s_acc[(t / NV) * BATCH * NV + tid * NV + (t % NV)] = 0.f;
+        }
+        __syncthreads();
+
+        // ---- walk the staged entries whose log slots exist for this wave's quadrants ----
+        const uint32_t kbase = hi - 1u - (uint32_t)i * BATCH;  // list position of staged entry j = kbase - j (scalar)
+#pragma unroll
+        for (int w = 0; w < SW; w++) {
+            unsigned long long bq[NQ];
+            unsigned long long U = 0ull;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                bq[q] = __builtin_amdgcn_ballot_w64(((s_row[64 * w + lane] >> (28 + q_first + q)) & 1u) != 0u);
+                U |= bq[q];
+            }
+            if (U == 0ull) continue;
+            int jj = (int)__builtin_ctzll(U);
+            U &= U - 1ull;
+            int j = 64 * w + jj;
+            // an entry's masks: NQ consecutive 64-bit words, read with a scalar load (uniform address, read-only memory)
+            struct Masks { unsigned long long m[NQ]; };
+            auto load_masks = [&](int jx) -> Masks {
+                Masks r;
+                const unsigned long long* p = logw + 4 * (size_t)(kbase - (uint32_t)jx);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) r.m[q] = p[q];
+                return r;
+            };
+            // (two register sets taking turns, as in render_backward_kernel)
+            float4 opA0 = s_a[j], opB0 = s_b[j], opA1, opB1;
+            float2 opC0 = s_c[j], opC1;
+            Masks opM0 = load_masks(j), opM1;
+            auto entry = [&](const float4& a, const float4& b, const float2& c, const Masks& mk, float4& na, float4& nb, float2& nc,
+                             Masks& nm) __attribute__((always_inline)) -> bool {
+                // this entry's masks: the forward's if it wrote one (staged bit), else nothing
+                unsigned long long mq[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) mq[q] = ((bq[q] >> jj) & 1ull) ? mk.m[q] : 0ull;
+                const int jcur = j;
+                // the NEXT entry's operands and masks are requested first: the round trips hide behind this entry's work
+                const bool more = U != 0ull;
+                const int jjn = more ? (int)__builtin_ctzll(U) : jj;
+                U &= U - 1ull;
+                const int jn = 64 * w + jjn;
+                na = s_a[jn]; nb = s_b[jn]; nc = s_c[jn];
+                nm = load_masks(jn);
+                jj = jjn; j = jn;
+                const float dy = a.y - pyf;  // the wave's quadrants lie side by side: one dy per lane
+                const float cyy = (b.x * dy) * dy;  // shared by the wave's quadrants (same operation order as the forward's)
+                // one (entry, quadrant) visit with the forward's mask m_c != 0: what the quadrant leaves for the sums
+                auto visit = [&](auto Q, unsigned long long m_c, float& Wq, float& WXq, float& DXq, float& ATq) __attribute__((always_inline)) {
+                    constexpr int q = decltype(Q)::value;
+                    float dx;
+                    asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(a.x), "v"((NQ > 1 && q) ? pxf1 : pxf0));
+                    // as the forward (CONTRACT-FMA); G from the hardware exp2: <= 1e-6 relative off the forward's gsr_expf_blend
+                    const float qq = __builtin_fmaf(a.z * dx, dx, cyy);
+                    const float power = __builtin_fmaf(-0.5f, qq, -((a.w * dx) * dy));
+                    const float G = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
+                    const float alpha = fminf(0.99f, b.y * G);
+                    // all 64 lanes run the same straight-line code; a lane outside the mask is given alpha = G = 0 (whatever its own
+                    // power gave: the select discards it): T / (1 - 0) = T, its terms vanish, `behind` stays
+                    float Ge, ae;
+                    asm("v_cndmask_b32 %0, 0, %2, %4\n v_cndmask_b32 %1, 0, %3, %4" : "=&v"(Ge), "=v"(ae) : "v"(G), "v"(alpha), "s"(m_c));
+                    const float oma = 1.f - ae;
+                    const float inv = __builtin_amdgcn_rcpf(oma);
+                    T[q] = T[q] * inv;  // T / (1 - alpha), backward.cu:502
+                    // accum . dL/dpixel carried as one scalar per pixel (see render_backward_kernel); recurrence accum' = accum +
+                    // alpha (c . dL - accum), backward.cu:515 regrouped: one fma on the difference dL/dalpha needs anyway
+                    const float cdl = __builtin_fmaf(c.y, dL2[q], __builtin_fmaf(c.x, dL1[q], b.w * dL0[q]));
+                    const float diff = cdl - behind[q];
+                    behind[q] = __builtin_fmaf(ae, diff, behind[q]);
+                    float dL_dalpha = diff * T[q];
+                    dL_dalpha = __builtin_fmaf(-tfbg[q], inv, dL_dalpha);  // (-T_final / (1 - alpha)) * (bg . dL/dpixel)
+                    Wq = Ge * dL_dalpha;
+                    WXq = Wq * dx;
+                    DXq = dx;
+                    ATq = ae * T[q];
+                };
+                if constexpr (NQ == 1) {
+                    if (mq[0] != 0ull) {
+                        float W0, WX0, DX0, AT0;
+                        visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
+                        const float wdx = WX0, wdy = W0 * dy;
+                        const float tot = wave_sum9_scatter(W0, wdx, wdy, wdx * DX0, wdx * dy, wdy * dy, AT0 * dL0[0], AT0 * dL1[0],
+                                                            AT0 * dL2[0], M0, M2);
+                        if (writer) atomicAdd(&my_acc[jcur * NV + my_slot], tot);  // LDS
+                    }
+                } else if ((mq[0] | mq[NQ - 1]) != 0ull) {  // wave-uniform
+                    // the lane's two pixels share dy: the y moments of their sum are products of the x moments with dy
+                    float sw, swx, sxx, c0, c1, c2;
+                    float W0, WX0, DX0, AT0, W1, WX1, DX1, AT1;
+                    if (mq[0] != 0ull) {
+                        visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
+                        if (mq[NQ - 1] != 0ull) {
+                            visit(std::integral_constant<int, NQ - 1>{}, mq[NQ - 1], W1, WX1, DX1, AT1);
+                            sw = W0 + W1;
+                            swx = WX0 + WX1;
+                            sxx = __builtin_fmaf(WX1, DX1, WX0 * DX0);
+                            c0 = __builtin_fmaf(AT1, dL0[NQ - 1], AT0 * dL0[0]);
+                            c1 = __builtin_fmaf(AT1, dL1[NQ - 1], AT0 * dL1[0]);
+                            c2 = __builtin_fmaf(AT1, dL2[NQ - 1], AT0 * dL2[0]);
+                        } else {
+                            sw = W0; swx = WX0; sxx = swx * DX0;
+                            c0 = AT0 * dL0[0]; c1 = AT0 * dL1[0]; c2 = AT0 * dL2[0];
+                        }
+                    } else {
+                        visit(std::integral_constant<int, NQ - 1>{}, mq[NQ - 1], W1, WX1, DX1, AT1);
+                        sw = W1; swx = WX1; sxx = swx * DX1;
+                        c0 = AT1 * dL0[NQ - 1]; c1 = AT1 * dL1[NQ - 1]; c2 = AT1 * dL2[NQ - 1];
+                    }
+                    const float swy = sw * dy;
+                    const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M2);
+                    if (writer) atomicAdd(&my_acc[jcur * NV + my_slot], tot);  // LDS
+                }
+                return more;
+            };
+            while (entry(opA0, opB0, opC0, opM0, opA1, opB1, opC1, opM1) && entry(opA1, opB1, opC1, opM1, opA0, opB0, opC0, opM0)) {}
+        }
+        __syncthreads();
+        // ---- flush: entry `tid` of the batch -> one gradient row ----
+        if (tid < BATCH) {
+            const uint32_t frow = s_row[tid] & GSR_NO_ROW;
+            if (frow != GSR_NO_ROW) {
+                float r[NV];
+#pragma unroll
+                for (int t = 0; t < NV; t++) r[t] = NACC == 1 ? s_acc[tid * NV + t] : s_acc[tid * NV + t] + s_acc[(BATCH + tid) * NV + t];
+                const float4 a = s_a[tid];
+                const float4 b = s_b[tid];
+                const float op = b.y, cx = a.z, cy = a.w, cz = b.x;
+                const float gmx = op * (-cx * r[1] - cy * r[2]) * ddelx_dx;
+                const float gmy = op * (-cz * r[2] - cy * r[1]) * ddely_dy;
+                const float hop = -0.5f * op;
+                const float out9[9] = {gmx, gmy, hop * r[3], hop * r[4], hop * r[5], r[0], r[6], r[7], r[8]};
+                gsr_row_store(grad_rows, frow, out9);
+            }
+        }
+    }
+    // list entries behind every pixel's last contributor: zero rows (for those that own a row)
+    for (uint32_t e = hi + tid; e < total; e += NT) {
+        const uint32_t id = point_list[r0 + e];
+        const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
+        const float4 q0 = rec[0], q2 = rec[2], q3 = rec[3];
+        uint32_t mnx, mny, mxx, mxy;
+        gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
+        const uint32_t tilepos = (by - mny) * (mxx - mnx) + (bx - mnx);
+        uint32_t row;
+        if (__float_as_uint(q3.w) == 0u) {
+            const unsigned long long mask = ((unsigned long long)__float_as_uint(q3.z) << 32) | __float_as_uint(q3.y);
+            if (!((mask >> tilepos) & 1ull)) continue;
+            row = __float_as_uint(q3.x) + (uint32_t)__popcll(mask & ((1ull << tilepos) - 1ull));
+        } else
+            row = __float_as_uint(q3.x) + tilepos;
+        const float z[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        gsr_row_store(grad_rows, row, z);
+    }
+}
+
 }  // namespace
 
 // mean_list: mean length of the reference's tile lists (num_rendered / tiles), known to the host.  BWD_NQ: 1 / 2 force a work split,
 // 0 (default) picks two quadrants per wave when the lists are short (see the header).
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                                const uint32_t* order, float* grad_rows, float mean_list, hipStream_t s)
+                                const uint32_t* order, float* grad_rows, float mean_list, const unsigned long long* blend_log,
+                                hipStream_t s)
 {
     if (!gsr_variant("LPT", 1)) order = nullptr;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
@@ -446,6 +728,15 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
     // 2M, 1866: 0.745 vs 0.636; and 10k Gaussians at 256x256, 256 tiles: 0.121 vs 0.064; with the final kernels, mean list ~400: 300k Gaussians at
     // 800x800, 2,500 tiles: 0.339 vs 0.192; 150k at 640x360, 920 tiles: 0.394 vs 0.204 -- few tiles leave the longest list's waves alone on the chip)
     if (nq != 1 && nq != 2) nq = (mean_list < (float)gsr_variant("BWD_NQ_LIST", 700) && gx * gy >= gsr_variant("BWD_NQ_TILES", 4096)) ? 2 : 1;
+    if (blend_log) {  // the forward logged its blend decisions (render_forward.hip): the walk reads them instead of re-deriving them
+        if (nq == 2)
+            hipLaunchKernelGGL((render_backward_log_kernel<2>), dim3(gx * gy), dim3(128), (size_t)gsr_variant("BWD_PADLDS", 0), s, W, H, gx, gy, order, ranges,
+                               point_list, splat, bg, final_T, n_contrib, dL_dpix, blend_log, grad_rows);
+        else
+            hipLaunchKernelGGL((render_backward_log_kernel<1>), dim3(gx * gy), dim3(256), (size_t)gsr_variant("BWD_PADLDS", 0), s, W, H, gx, gy, order, ranges,
+                               point_list, splat, bg, final_T, n_contrib, dL_dpix, blend_log, grad_rows);
+        return;
+    }
     const bool fast = gsr_variant("BWD_FASTEXP", 1) != 0;
 #define GSR_BWD_LAUNCH(NQ_, F_)                                                                                                  \
     hipLaunchKernelGGL((render_backward_kernel<NQ_, F_>), dim3(gx * gy), dim3(64 * (4 / NQ_)), (size_t)gsr_variant("BWD_PADLDS", 0), s, W, H, gx, gy, order, ranges, \

@@ -14,17 +14,30 @@
 
 namespace {
 
+// Timing ablations of the blend log (results WRONG on purpose, never defined in the shipped build): -DGSR_FWD_LOG_ABLATE=n
+//   1: the stores without the mask (a constant is stored)   2: the mask without the stores
+#ifndef GSR_FWD_LOG_ABLATE
+#define GSR_FWD_LOG_ABLATE 0
+#endif
 #ifndef GSR_FWD_GROUP
 #define GSR_FWD_GROUP 4  // entries per turn of the walk (the all-pixels-done test runs once per turn)
 #endif
 
-template <bool QUAD>
+// LOG (QUAD only): the blend log.  Every (list entry, 8x8 quadrant) visit of the walk leaves the 64-bit mask of the lanes (pixels) that
+// blended the entry -- the outcome of every decision of forward.cu:332-352 for 64 pixels -- at blend_log[4 * (list position) + quadrant],
+// zero when none did.  The backward (render_backward.hip, log walk) reads the masks instead of re-deriving them: no range test, no
+// threshold test, no alpha test, no n_contrib bookkeeping, and the decisions are the forward's by construction.  The masks live in
+// scalar registers (a ballot), so they are written with SCALAR stores (s_store_dwordx2, no VALU slot; tools/smem_probe.hip: gfx950
+// executes them, the scalar cache writes back dirty bytes, ~0.1 us per record with the chip full) and flushed by s_dcache_wb at the
+// end of the wave.  Slots of visits that did not happen (quadrant out of the splat's reach, or behind the wave's exit) are never written:
+// the backward recomputes the reach bit and knows the exit from n_contrib.
+template <bool QUAD, bool LOG>
 __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, int gy, int wave8x8, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list,
                                                              const float* __restrict__ splat, const float* __restrict__ bg,
                                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                             float* __restrict__ out_color)
+                                                             float* __restrict__ out_color, unsigned long long* blend_log)
 {
     __shared__ float4 s_a[256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)];  // mx, my, conic.x, conic.y          (+4: padding entries for the unrolled walk)
     __shared__ float4 s_b[256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
@@ -62,6 +75,15 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
         s_a[256 + tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
         s_b[256 + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
     }
+    // LOG: the slot of (list position 0 of this tile, this wave's quadrant) -- gsr_blend_log_slot, common.h; entry j of round i lies
+    // 32 * (256 i + j) bytes further.  A padding entry of the unrolled walk writes to the tile's spare position (one behind its list).
+    const uint32_t wave_s = __builtin_amdgcn_readfirstlane((uint32_t)wave);
+    const unsigned long long* log_tile = LOG ? blend_log + gsr_blend_log_slot(r0, tile, wave_s) : nullptr;
+    const uint32_t log_spare = 32u * (uint32_t)total;
+    unsigned long long pend_m[GSR_FWD_GROUP];  // masks of the group walked last, stored during the next one
+    uint32_t pend_o[GSR_FWD_GROUP];
+#pragma unroll
+    for (int v = 0; v < GSR_FWD_GROUP; v++) { pend_m[v] = 0ull; pend_o[v] = log_spare; }
     for (int i = 0; QUAD && i < rounds; i++) {
         // QUAD: every staged entry is tested against the four 8x8 quadrants of the tile (gsr_quad_mask) and stays at its staged
         // position; a wave walks only the entries that can reach ITS block, picking them from the ballot masks with scalar bit
@@ -99,9 +121,13 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             while (m != 0ull) {
                 // the next (up to) four entries of this wave; missing ones are the padding entry
                 int jj[GSR_FWD_GROUP];
+                uint32_t lo[GSR_FWD_GROUP];  // LOG: where each visit's mask goes (byte offset from log_tile)
+                unsigned long long new_m[GSR_FWD_GROUP];
 #pragma unroll
                 for (int u = 0; u < GSR_FWD_GROUP; u++) {
-                    jj[u] = m != 0ull ? 64 * w + (int)__builtin_ctzll(m) : 256 + u;
+                    const bool real = m != 0ull;
+                    jj[u] = real ? 64 * w + (int)__builtin_ctzll(m) : 256 + u;
+                    if (LOG) lo[u] = real ? 32u * (uint32_t)(256 * i + jj[u]) : log_spare;
                     m &= m - 1ull;
                 }
 #pragma unroll
@@ -114,29 +140,93 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                     const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
                     const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
                     const bool maybe = power >= b.z;
-                    if (gsr_any(maybe)) {  // wave-uniform
-                        if (maybe && px != PARKED && power <= 0.0f) {
-                            const float alpha = fminf(0.99f, b.y * gsr_expf_blend(power));
-                            if (alpha >= 1.0f / 255.0f) {
-                                const float test_T = T * (1.0f - alpha);
-                                if (test_T < 0.0001f) {
-                                    px = PARKED;  // done
-                                } else {
-                                    const float4 c = s_c[j];
-                                    // CONTRACT-FMA: C += (f*alpha)*T
-                                    C0 = __builtin_fmaf(c.x * alpha, T, C0);
-                                    C1 = __builtin_fmaf(c.y * alpha, T, C1);
-                                    C2 = __builtin_fmaf(c.z * alpha, T, C2);
-                                    T = test_T;
-                                    last_contributor = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
+                    if (!LOG) {
+                        if (gsr_any(maybe)) {  // wave-uniform
+                            if (maybe && px != PARKED && power <= 0.0f) {
+                                const float alpha = fminf(0.99f, b.y * gsr_expf_blend(power));
+                                if (alpha >= 1.0f / 255.0f) {
+                                    const float test_T = T * (1.0f - alpha);
+                                    if (test_T < 0.0001f) {
+                                        px = PARKED;  // done
+                                    } else {
+                                        const float4 c = s_c[j];
+                                        // CONTRACT-FMA: C += (f*alpha)*T
+                                        C0 = __builtin_fmaf(c.x * alpha, T, C0);
+                                        C1 = __builtin_fmaf(c.y * alpha, T, C1);
+                                        C2 = __builtin_fmaf(c.z * alpha, T, C2);
+                                        T = test_T;
+                                        last_contributor = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
+                                    }
                                 }
                             }
                         }
+                    } else {
+                        // LOG: the same decisions (forward.cu:332-352) as 64-bit LANE MASKS in scalar registers -- each compare is its own
+                        // ballot, the conjunctions are scalar ANDs -- so the mask of the lanes that blend is there for the log without a
+                        // VALU slot, and the blend itself runs under EXEC = that mask (one asm block: the compiler cannot express "these
+                        // lanes" from a scalar mask without rebuilding it per lane).  alpha / test_T are evaluated by all lanes; a lane
+                        // outside the masks keeps nothing of them.  Same arithmetic per blending lane as the nested form: bit-identical.
+                        unsigned long long blended = 0ull;
+                        const unsigned long long m_maybe = __builtin_amdgcn_ballot_w64(maybe);
+                        if (m_maybe != 0ull) {  // wave-uniform
+                            const unsigned long long m1 = m_maybe & __builtin_amdgcn_ballot_w64(px != PARKED) & __builtin_amdgcn_ballot_w64(power <= 0.0f);
+                            const float alpha = fminf(0.99f, b.y * gsr_expf_blend(power));
+                            const unsigned long long m2 = m1 & __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
+                            const float test_T = T * (1.0f - alpha);
+                            const unsigned long long m_done = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                            blended = m2 & ~m_done;
+                            const float4 c = s_c[j];
+                            float t0, t1, t2;
+                            asm volatile(
+                                "v_cndmask_b32 %[px], %[px], %[parked], %[md]\n"   // done: parked
+                                "s_mov_b64 exec, %[mb]\n"
+                                "v_mul_f32 %[t0], %[cx], %[al]\n"                  // CONTRACT-FMA: C += (f*alpha)*T
+                                "v_mul_f32 %[t1], %[cy], %[al]\n"
+                                "v_mul_f32 %[t2], %[cz], %[al]\n"
+                                "v_fmac_f32 %[C0], %[t0], %[T]\n"
+                                "v_fmac_f32 %[C1], %[t1], %[T]\n"
+                                "v_fmac_f32 %[C2], %[t2], %[T]\n"
+                                "v_mov_b32 %[T], %[tT]\n"
+                                "v_add_u32 %[lc], 1, %[bw]\n"                      // = `contributor` of forward.cu:322
+                                "s_mov_b64 exec, -1\n"
+                                : [px] "+v"(px), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [T] "+v"(T), [lc] "+v"(last_contributor),
+                                  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                                : [parked] "v"(PARKED), [md] "s"(m_done), [mb] "s"(blended), [cx] "v"(c.x), [cy] "v"(c.y), [cz] "v"(c.z),
+                                  [al] "v"(alpha), [tT] "v"(test_T), [bw] "v"(b.w));
+                        }
+                        // the masks of this group are stored while the NEXT group computes (below): a scalar store counts on lgkmcnt like
+                        // an LDS read, so a store issued here would be waited for by the next entry's operand reads
+                        new_m[u] = blended;
                     }
+                    if (LOG && u == 0) {
+                        // the previous group's four masks (first turn: four zero masks to the spare slot)
+#pragma unroll
+                        for (int v = 0; v < GSR_FWD_GROUP; v++)
+                            if (GSR_FWD_LOG_ABLATE != 2) asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(pend_m[v]), "s"(log_tile), "s"(pend_o[v]) : "memory");
+                    }
+                    if (LOG && u == 1) {
+                        // A scalar store reads its data registers some time AFTER it issues (seen as a handful of wrong masks when the
+                        // allocator reused them at once): the eight data and four offset registers stay untouched until the stores have
+                        // completed.  Here the second entry's operands have just arrived from LDS, so the counter is (nearly) at zero anyway.
+                        static_assert(GSR_FWD_GROUP == 4, "keep-alive list below");
+                        asm volatile("s_waitcnt lgkmcnt(0) ; keepalive %0 %1 %2 %3 %4 %5 %6 %7 %8" ::"s"(pend_m[0]), "s"(pend_m[1]), "s"(pend_m[2]), "s"(pend_m[3]), "s"(pend_o[0]),
+                                     "s"(pend_o[1]), "s"(pend_o[2]), "s"(pend_o[3]), "s"(log_tile), "v"(power) : "memory");
+                    }
+                }
+                if (LOG) {
+#pragma unroll
+                    for (int v = 0; v < GSR_FWD_GROUP; v++) { pend_m[v] = new_m[v]; pend_o[v] = lo[v]; }
                 }
                 if (!gsr_any(px != PARKED)) { wave_done = true; break; }
             }
         }
+    }
+    if (LOG && total > 0) {  // the last group's masks (an empty tile has range (0, 0): its "spare slot" would be somebody's list position)
+#pragma unroll
+        for (int v = 0; v < GSR_FWD_GROUP; v++)
+            if (GSR_FWD_LOG_ABLATE != 2) asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(pend_m[v]), "s"(log_tile), "s"(pend_o[v]) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(pend_m[0]), "s"(pend_m[1]), "s"(pend_m[2]), "s"(pend_m[3]), "s"(pend_o[0]), "s"(pend_o[1]),
+                     "s"(pend_o[2]), "s"(pend_o[3]), "s"(log_tile) : "memory");
     }
     for (int i = 0; !QUAD && i < rounds; i++) {
         // gather this batch's records and decide, per entry, whether the tile can see it at all
@@ -221,21 +311,29 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
         out_color[plane + pix_id] = C1 + T * bg[1];
         out_color[2 * plane + pix_id] = C2 + T * bg[2];
     }
+    if (LOG) asm volatile("s_waitcnt lgkmcnt(0)\n s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");  // the scalar stores leave the scalar cache
 }
 
 }  // namespace
 
+// blend_log: the R-sized mask array of the binning buffer (BinLayout::blend_log), or NULL (no log: the backward then re-derives every
+// decision).  Written only by the quadrant walk (GSR_QUAD=1, GSR_WAVE8X8=1, the default): gsr_blend_log_enabled (api.hip) says whether it is.
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
-                               hipStream_t s)
+                               unsigned long long* blend_log, hipStream_t s)
 {
     if (!gsr_variant("LPT", 1)) order = nullptr;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
     const int wave8x8 = gsr_variant("WAVE8X8", 1);
-    if (wave8x8 && gsr_variant("QUAD", 1))
-        hipLaunchKernelGGL((render_forward_kernel<true>), dim3(gx * gy), dim3(256), (size_t)gsr_variant("FWD_PADLDS", 0), s, W, H, gx, gy, gsr_variant("QUAD", 1) == 2 ? 2 : 1, order, ranges, point_list, splat, bg,
-                           final_T, n_contrib, out_color);
-    else
-        hipLaunchKernelGGL((render_forward_kernel<false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
-                           final_T, n_contrib, out_color);
+    if (wave8x8 && gsr_variant("QUAD", 1)) {
+        const int mode = gsr_variant("QUAD", 1) == 2 ? 2 : 1;
+        if (blend_log && mode == 1)
+            hipLaunchKernelGGL((render_forward_kernel<true, true>), dim3(gx * gy), dim3(256), (size_t)gsr_variant("FWD_PADLDS", 0), s, W, H, gx, gy, mode, order, ranges,
+                               point_list, splat, bg, final_T, n_contrib, out_color, blend_log);
+        else
+            hipLaunchKernelGGL((render_forward_kernel<true, false>), dim3(gx * gy), dim3(256), (size_t)gsr_variant("FWD_PADLDS", 0), s, W, H, gx, gy, mode, order, ranges,
+                               point_list, splat, bg, final_T, n_contrib, out_color, (unsigned long long*)nullptr);
+    } else
+        hipLaunchKernelGGL((render_forward_kernel<false, false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
+                           final_T, n_contrib, out_color, (unsigned long long*)nullptr);
 }
