@@ -77,6 +77,7 @@ PROTOTYPES = {
     "gsr_debug_export": (c_int, [c_int, c_i64, c_int, c_int] + [c_void_p] * 17),
     "gsr_debug_capture_sums": (c_int, [c_void_p]),
     "gsr_debug_knn_counter": (c_int, [c_void_p]),
+    "gsr_debug_blend_profile": (c_int, [ctypes.POINTER(ctypes.c_uint64)]),
     "gsr_build_info": (ctypes.c_char_p, []),
     "gsr_set_variant": (c_int, [ctypes.c_char_p, c_int]),
     "gsr_get_variant": (c_int, [ctypes.c_char_p, c_int]),

@@ -486,7 +486,7 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
         const uint32_t* order = (R > 0 && gsr_variant("BIN", 1)) ? (const uint32_t*)(b + B.order) : nullptr;
         unsigned long long* blend_log = (R > 0 && gsr_blend_log_enabled()) ? (unsigned long long*)(b + B.blend_log) : nullptr;
         gsr_launch_render_forward(W, H, ranges, point_list, (const float*)(g + G.splat), background, (float*)(im + I.final_T),
-                                  (uint32_t*)(im + I.n_contrib), out_color, order, blend_log, s);
+                                  (uint32_t*)(im + I.n_contrib), out_color, order, blend_log, (uint32_t*)(im + I.quad_hi), s);
     }
     return check_hip("forward_render");
 }
@@ -605,7 +605,8 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
                                    (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
                                    gsr_variant("BIN", 1) ? (const uint32_t*)(b + B.order) : nullptr, (float*)scratch,
                                    (float)R / (float)(gx * gy),
-                                   gsr_blend_log_enabled() ? (const unsigned long long*)(b + B.blend_log) : nullptr, s);
+                                   gsr_blend_log_enabled() ? (const unsigned long long*)(b + B.blend_log) : nullptr,
+                                   (const uint32_t*)(im + I.quad_hi), s);
     }
     a.cov3D_in = cov3D_precomp ? cov3D_precomp : (const float*)(g + G.cov3D);
     a.clamped = (const uint8_t*)(g + G.clamped); a.splat = (const float*)(g + G.splat);
@@ -943,6 +944,18 @@ int gsr_debug_capture_sums(float* sums)
 {
     g_capture_sums = sums;
     return 0;
+}
+
+// Phase profile of the blend kernels: sixteen wave-cycle sums, [0..7] the backward's log walk (render_backward.hip), [8..15] the forward's
+// quadrant walk (render_forward.hip), GSR_LOG_PROFILE; returns 1 if the library was built with the profile, 0 if not (all zeros),
+// negative on error.  Synchronises the device.
+int gsr_debug_blend_profile(uint64_t* counters16)
+{
+    if (!counters16) return fail(-1, "counters16 is NULL");
+    if (hipDeviceSynchronize() != hipSuccess) return check_hip("gsr_debug_blend_profile");
+    const int rc = gsr_blend_profile_fetch((unsigned long long*)counters16);
+    const int rf = gsr_forward_profile_fetch((unsigned long long*)counters16 + 8);
+    return (rc < 0 || rf < 0) ? fail(-4, "gsr_debug_blend_profile: symbol copy failed") : rc;
 }
 
 int gsr_debug_knn_counter(uint64_t* counter)

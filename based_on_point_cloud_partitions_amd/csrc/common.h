@@ -38,7 +38,7 @@ struct GeomLayout {
         wg_first /* work split of the per-Gaussian backward: first Gaussian of every workgroup (gsr_part_*) */, bytes;
 };
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, bytes;
+    size_t final_T, n_contrib, ranges, quad_hi, bytes;
 };
 #define GSR_BAND_COUNTERS 64  // most bands; band_mem = [64 unused words][nb * P ids]
 // order[] = [T tile ids by descending list length][64 + 64 counts, one per band, of the tiles whose lists a workgroup sorts
@@ -155,6 +155,7 @@ static inline ImageLayout gsr_image_layout(int W, int H)
     L.final_T = o; o = gsr_align(o + n * 4);
     L.n_contrib = o; o = gsr_align(o + n * 4);
     L.ranges = o; o = gsr_align(o + t * 8);
+    L.quad_hi = o; o = gsr_align(o + t * 16);  // per tile: largest n_contrib of each 8x8 quadrant (written with the blend log, render_forward.hip)
     L.bytes = o;
     return L;
 }
@@ -193,20 +194,13 @@ static inline BinLayout gsr_bin_layout(long R, int P, int W, int H)
     L.vals_a = o; o = gsr_align(o + r * 4);
     L.vals_b = o; o = gsr_align(o + r * 4);
     L.hist_blocks = o; o = gsr_align(o + (size_t)L.sort_blocks * 256 * 4);
-    {   // blend log (render_forward.hip -> render_backward.hip): four 64-bit lane masks per list position, one spare position per tile
-        const size_t t = (size_t)((W + GSR_TILE_X - 1) / GSR_TILE_X) * ((H + GSR_TILE_Y - 1) / GSR_TILE_Y);
-        L.blend_log = o; o = gsr_align(o + (r + t + 1) * 32);
-    }
+    L.blend_log = o; o = gsr_align(o + r * 32);  // blend log (render_forward.hip -> render_backward.hip): four 64-bit lane masks per list position
     L.bytes = o;
     return L;
 }
 
-// Blend log: index (in 64-bit words) of the mask of (tile, list position r0 + k = first position of the tile + k, quadrant q); position
-// `list length` of a tile is its spare slot (written by the padding entries of the forward's unrolled walk, never read).
-__host__ __device__ __forceinline__ size_t gsr_blend_log_slot(uint32_t r0, uint32_t tile, uint32_t q)
-{
-    return ((size_t)r0 + (size_t)tile) * 4 + q;
-}
+// Blend log: index (in 64-bit words) of the mask of (list position p = first position of the tile + k, quadrant q)
+__host__ __device__ __forceinline__ size_t gsr_blend_log_slot(uint32_t p, uint32_t q) { return (size_t)p * 4 + q; }
 
 // rasterizer_impl.cu:35-50 (number of key bits that hold the tile id)
 static inline uint32_t gsr_higher_msb(uint32_t n)
@@ -275,11 +269,13 @@ void gsr_launch_tile_binning_tail(int P, int W, int H, const float* splat, uint3
 void gsr_launch_tile_ranges(uint32_t R, const uint64_t* keys_sorted, uint32_t* ranges, uint32_t ntiles, hipStream_t s);
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
-                               unsigned long long* blend_log, hipStream_t s);
+                               unsigned long long* blend_log, uint32_t* quad_hi, hipStream_t s);
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
                                 const uint32_t* order, float* grad_rows, float mean_list, const unsigned long long* blend_log,
-                                hipStream_t s);
+                                const uint32_t* quad_hi, hipStream_t s);
+int gsr_blend_profile_fetch(unsigned long long* out8);
+int gsr_forward_profile_fetch(unsigned long long* out8);  // render_forward.hip: the same for the forward's quadrant walk  // render_backward.hip: phase profile of the log walk (profiling builds)
 bool gsr_blend_log_enabled();                 // the forward's quadrant walk logs its blend decisions for the backward (render_forward.hip)
 int gsr_variant(const char* name, int dflt);  // experiment switch read from the environment (GSR_<name>)
 bool gsr_cull_enabled();                      // tile lists without the instances the splat's alpha >= 1/255 ellipse cannot reach

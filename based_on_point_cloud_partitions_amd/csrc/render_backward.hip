@@ -431,6 +431,16 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
 }
 
 
+// Phase profile of the log walk (make EXTRA=-DGSR_LOG_PROFILE=1, never in the shipped build): wave-cycles (s_memtime) per phase, summed over all
+// waves of all launches since the last gsr_debug_blend_profile call: [0] whole wave, [1] prologue, [2] staging loads + tests, [3] wait at the
+// "previous batch flushed" barrier, [4] LDS writes + barrier, [5] walk, [6] wait at the end-of-walk barrier (the other wave is still walking),
+// [7] flush + zero rows.
+#ifndef GSR_LOG_PROFILE
+#define GSR_LOG_PROFILE 0
+#endif
+__device__ unsigned long long g_blend_prof[8];  // ([4] holds the zero rows + end of the wave in profiling builds: the LDS writes are folded into [3])
+#define GSR_PROF_MARK(slot) do { if (GSR_LOG_PROFILE) { const long long t_ = clock64(); prof[slot] += (unsigned long long)(t_ - t_last); t_last = t_; } } while (0)
+
 // ---- the log walk (round 5) ----------------------------------------------------------------------------------------------------------
 // The same kernel fed with the forward's blend log (render_forward.hip): for every (list entry, quadrant) visit the forward made, the
 // 64-bit mask of the pixels that blended the entry.  Everything render_backward_kernel re-derives per visit -- is the entry in front of
@@ -446,7 +456,7 @@ template <int NQ>
 __global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE ? GSR_BWD_WPE : 8)))
 render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ranges,
                            const uint32_t* __restrict__ point_list, const float* __restrict__ splat, const float* __restrict__ bg,
-                           const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                           const float* __restrict__ final_Ts, const uint32_t* __restrict__ quad_hi,
                            const float* __restrict__ dL_dpixels, const unsigned long long* __restrict__ blend_log,
                            float* __restrict__ grad_rows)
 {
@@ -460,7 +470,6 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
     __shared__ uint32_t s_row[BATCH];  // gradient row index | (quadrants whose log slot the forward wrote) << 28
     constexpr int NACC = NQ == 2 ? 1 : 2;
     __shared__ float s_acc[NACC * BATCH * NV];
-    uint32_t* s_hi = reinterpret_cast<uint32_t*>(s_acc);  // [4]: largest n_contrib of each quadrant, only before the first round
 
     const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;
     const uint32_t bx = tile % (uint32_t)gx, by = tile / (uint32_t)gx;
@@ -470,6 +479,14 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
     const uint32_t r1 = __builtin_amdgcn_readfirstlane(ranges[2 * tile + 1]);
     const uint32_t total = r1 - r0;
     if (total == 0) return;
+    // largest n_contrib of each quadrant (stored by the forward beside its log): how far the quadrant's log goes.  Scalar loads: the
+    // tile's bounds are known before anything per pixel has been read
+    const uint32_t h0 = __builtin_amdgcn_readfirstlane(quad_hi[4 * tile]), h1 = __builtin_amdgcn_readfirstlane(quad_hi[4 * tile + 1]);
+    const uint32_t h2 = __builtin_amdgcn_readfirstlane(quad_hi[4 * tile + 2]), h3 = __builtin_amdgcn_readfirstlane(quad_hi[4 * tile + 3]);
+    const uint32_t hi = max(max(h0, h1), max(h2, h3));  // number of list entries that matter to any pixel of the tile
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = GSR_LOG_PROFILE ? clock64() : 0;
+    const long long t_begin = t_last;
 
     const uint32_t lx = lane & 7, ly = lane >> 3;
     const int q_first = wave * NQ;
@@ -489,19 +506,33 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
         const size_t pix_id = (size_t)W * py + px;
         const float Tf = inside ? final_Ts[pix_id] : 0.f;
         T[q] = Tf;
-        uint32_t m = inside ? n_contrib[pix_id] : 0u;
         dL0[q] = dL1[q] = dL2[q] = 0.f;
         if (inside) { dL0[q] = dL_dpixels[pix_id]; dL1[q] = dL_dpixels[plane + pix_id]; dL2[q] = dL_dpixels[2 * plane + pix_id]; }
         tfbg[q] = Tf * (((0.f + bg0 * dL0[q]) + bg1 * dL1[q]) + bg2 * dL2[q]);  // T_final * (bg . dL/dpixel), backward.cu:526-530
         behind[q] = 0.f;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-        if (lane == 0) s_hi[q_first + q] = m;  // the quadrant's last contributor: the forward wave walked at least this far
     }
-    __syncthreads();
-    const uint32_t h0 = __builtin_amdgcn_readfirstlane(s_hi[0]), h1 = __builtin_amdgcn_readfirstlane(s_hi[1]);
-    const uint32_t h2 = __builtin_amdgcn_readfirstlane(s_hi[2]), h3 = __builtin_amdgcn_readfirstlane(s_hi[3]);
-    const uint32_t hi = max(max(h0, h1), max(h2, h3));  // number of list entries that matter to any pixel of the tile
+    // list entries behind every pixel's last contributor: zero rows (for those that own a row).  At the END of the kernel: written first
+    // (measured, round 5: +0.027 ms) their stores sit in the memory pipeline in front of the first batch's loads
+    auto zero_rows = [&]() __attribute__((always_inline)) {
+        for (uint32_t e = hi + tid; e < total; e += NT) {
+            const uint32_t id = point_list[r0 + e];
+            const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
+            const float4 q0 = rec[0], q2 = rec[2], q3 = rec[3];
+            uint32_t mnx, mny, mxx, mxy;
+            gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
+            const uint32_t tilepos = (by - mny) * (mxx - mnx) + (bx - mnx);
+            uint32_t row;
+            if (__float_as_uint(q3.w) == 0u) {
+                const unsigned long long mask = ((unsigned long long)__float_as_uint(q3.z) << 32) | __float_as_uint(q3.y);
+                if (!((mask >> tilepos) & 1ull)) continue;
+                row = __float_as_uint(q3.x) + (uint32_t)__popcll(mask & ((1ull << tilepos) - 1ull));
+            } else
+                row = __float_as_uint(q3.x) + tilepos;
+            const float z[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            gsr_row_store(grad_rows, row, z);
+        }
+    };
+    GSR_PROF_MARK(1);
 
     unsigned long long M0 = 0xAAAAAAAAAAAAAAAAull, M2 = 0x0004000400040004ull;
     asm volatile("" : "+s"(M0), "+s"(M2));  // kept as two register PAIRS (the halves are equal: the compiler would rebuild the pair per use)
@@ -510,8 +541,10 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
     float* my_acc = s_acc + (NQ == 2 ? 0 : (wave >> 1) * BATCH * NV);
     const int rounds = (int)((hi + BATCH - 1) / BATCH);
     // the masks of (list position 0 of the tile, this wave's first quadrant); position k lies 4 k words further
-    const unsigned long long* logw = blend_log + gsr_blend_log_slot(r0, tile, (uint32_t)q_first);
+    const unsigned long long* logw = blend_log + gsr_blend_log_slot(r0, (uint32_t)q_first);
 
+    // (the next round's Gaussian ids loaded a round ahead -- one of the two dependent load latencies of a staging round behind the
+    // previous walk -- measured, round 5: 0.2913 vs 0.2917 ms, not kept)
     for (int i = 0; i < rounds; i++) {
         // ---- stage this batch (back to front): as render_backward_kernel, plus: a quadrant bit is kept only for k < the quadrant's last
         // contributor ----
@@ -547,7 +580,9 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
             }
             if (!keep) row = GSR_NO_ROW;
         }
+        GSR_PROF_MARK(2);
         __syncthreads();  // previous batch flushed
+        GSR_PROF_MARK(3);
         if (tid < BATCH) {
             s_a[tid] = q0;
             s_b[tid] = make_float4(q1.x, q1.y, 0.f, q1.z);
@@ -557,6 +592,7 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
             for (int t = 0; t < NACC * NV; t++) s_acc[(t / NV) * BATCH * NV + tid * NV + (t % NV)] = 0.f;
         }
         __syncthreads();
+        GSR_PROF_MARK(3);
 
         // ---- walk the staged entries whose log slots exist for this wave's quadrants ----
         const uint32_t kbase = hi - 1u - (uint32_t)i * BATCH;  // list position of staged entry j = kbase - j (scalar)
@@ -593,14 +629,17 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
 #pragma unroll
                 for (int q = 0; q < NQ; q++) mq[q] = ((bq[q] >> jj) & 1ull) ? mk.m[q] : 0ull;
                 const int jcur = j;
-                // the NEXT entry's operands and masks are requested first: the round trips hide behind this entry's work
                 const bool more = U != 0ull;
-                const int jjn = more ? (int)__builtin_ctzll(U) : jj;
-                U &= U - 1ull;
-                const int jn = 64 * w + jjn;
-                na = s_a[jn]; nb = s_b[jn]; nc = s_c[jn];
-                nm = load_masks(jn);
-                jj = jjn; j = jn;
+                // the NEXT entry's operands and masks, requested after this entry's quadrants and before its reduction: the registers
+                // are free by then and the round trips hide behind the reduction
+                auto request_next = [&]() __attribute__((always_inline)) {
+                    const int jjn = more ? (int)__builtin_ctzll(U) : jj;
+                    U &= U - 1ull;
+                    const int jn = 64 * w + jjn;
+                    na = s_a[jn]; nb = s_b[jn]; nc = s_c[jn];
+                    nm = load_masks(jn);
+                    jj = jjn; j = jn;
+                };
                 const float dy = a.y - pyf;  // the wave's quadrants lie side by side: one dy per lane
                 const float cyy = (b.x * dy) * dy;  // shared by the wave's quadrants (same operation order as the forward's)
                 // one (entry, quadrant) visit with the forward's mask m_c != 0: what the quadrant leaves for the sums
@@ -632,47 +671,48 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                     DXq = dx;
                     ATq = ae * T[q];
                 };
-                if constexpr (NQ == 1) {
-                    if (mq[0] != 0ull) {
-                        float W0, WX0, DX0, AT0;
-                        visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
-                        const float wdx = WX0, wdy = W0 * dy;
-                        const float tot = wave_sum9_scatter(W0, wdx, wdy, wdx * DX0, wdx * dy, wdy * dy, AT0 * dL0[0], AT0 * dL1[0],
-                                                            AT0 * dL2[0], M0, M2);
-                        if (writer) atomicAdd(&my_acc[jcur * NV + my_slot], tot);  // LDS
-                    }
-                } else if ((mq[0] | mq[NQ - 1]) != 0ull) {  // wave-uniform
-                    // the lane's two pixels share dy: the y moments of their sum are products of the x moments with dy
-                    float sw, swx, sxx, c0, c1, c2;
-                    float W0, WX0, DX0, AT0, W1, WX1, DX1, AT1;
-                    if (mq[0] != 0ull) {
-                        visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
-                        if (mq[NQ - 1] != 0ull) {
-                            visit(std::integral_constant<int, NQ - 1>{}, mq[NQ - 1], W1, WX1, DX1, AT1);
-                            sw = W0 + W1;
-                            swx = WX0 + WX1;
-                            sxx = __builtin_fmaf(WX1, DX1, WX0 * DX0);
-                            c0 = __builtin_fmaf(AT1, dL0[NQ - 1], AT0 * dL0[0]);
-                            c1 = __builtin_fmaf(AT1, dL1[NQ - 1], AT0 * dL1[0]);
-                            c2 = __builtin_fmaf(AT1, dL2[NQ - 1], AT0 * dL2[0]);
-                        } else {
-                            sw = W0; swx = WX0; sxx = swx * DX0;
-                            c0 = AT0 * dL0[0]; c1 = AT0 * dL1[0]; c2 = AT0 * dL2[0];
-                        }
-                    } else {
-                        visit(std::integral_constant<int, NQ - 1>{}, mq[NQ - 1], W1, WX1, DX1, AT1);
-                        sw = W1; swx = WX1; sxx = swx * DX1;
-                        c0 = AT1 * dL0[NQ - 1]; c1 = AT1 * dL1[NQ - 1]; c2 = AT1 * dL2[NQ - 1];
-                    }
+                auto reduce = [&](float sw, float swx, float sxx, float c0, float c1, float c2) __attribute__((always_inline)) {
+                    // the lane's pixels share dy: the y moments of their sum are products of the x moments with dy
                     const float swy = sw * dy;
                     const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M2);
                     if (writer) atomicAdd(&my_acc[jcur * NV + my_slot], tot);  // LDS
+                };
+                // Each case is ONE straight-line block (two quadrants: their two chains -- sub, 6 mul/fma, exp, select, rcp, 10 mul/fma --
+                // are independent and interleave) and ends in its own copy of the reduction: nothing is merged behind the branches.
+                float W0, WX0, DX0, AT0, W1, WX1, DX1, AT1;
+                if constexpr (NQ == 1) {
+                    if (mq[0] != 0ull) {
+                        visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
+                        request_next();
+                        reduce(W0, WX0, WX0 * DX0, AT0 * dL0[0], AT0 * dL1[0], AT0 * dL2[0]);
+                    } else
+                        request_next();
+                } else {
+                    const bool v0 = mq[0] != 0ull, v1 = mq[NQ - 1] != 0ull;
+                    if (v0 && v1) {
+                        visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
+                        visit(std::integral_constant<int, NQ - 1>{}, mq[NQ - 1], W1, WX1, DX1, AT1);
+                        request_next();
+                        reduce(W0 + W1, WX0 + WX1, __builtin_fmaf(WX1, DX1, WX0 * DX0), __builtin_fmaf(AT1, dL0[NQ - 1], AT0 * dL0[0]),
+                               __builtin_fmaf(AT1, dL1[NQ - 1], AT0 * dL1[0]), __builtin_fmaf(AT1, dL2[NQ - 1], AT0 * dL2[0]));
+                    } else if (v0) {
+                        visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
+                        request_next();
+                        reduce(W0, WX0, WX0 * DX0, AT0 * dL0[0], AT0 * dL1[0], AT0 * dL2[0]);
+                    } else if (v1) {
+                        visit(std::integral_constant<int, NQ - 1>{}, mq[NQ - 1], W1, WX1, DX1, AT1);
+                        request_next();
+                        reduce(W1, WX1, WX1 * DX1, AT1 * dL0[NQ - 1], AT1 * dL1[NQ - 1], AT1 * dL2[NQ - 1]);
+                    } else
+                        request_next();
                 }
                 return more;
             };
             while (entry(opA0, opB0, opC0, opM0, opA1, opB1, opC1, opM1) && entry(opA1, opB1, opC1, opM1, opA0, opB0, opC0, opM0)) {}
         }
+        GSR_PROF_MARK(5);
         __syncthreads();
+        GSR_PROF_MARK(6);
         // ---- flush: entry `tid` of the batch -> one gradient row ----
         if (tid < BATCH) {
             const uint32_t frow = s_row[tid] & GSR_NO_ROW;
@@ -690,24 +730,14 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                 gsr_row_store(grad_rows, frow, out9);
             }
         }
+        GSR_PROF_MARK(7);
     }
-    // list entries behind every pixel's last contributor: zero rows (for those that own a row)
-    for (uint32_t e = hi + tid; e < total; e += NT) {
-        const uint32_t id = point_list[r0 + e];
-        const float4* rec = reinterpret_cast<const float4*>(splat + (size_t)id * GSR_SPLAT_F);
-        const float4 q0 = rec[0], q2 = rec[2], q3 = rec[3];
-        uint32_t mnx, mny, mxx, mxy;
-        gsr_get_rect(q0.x, q0.y, __float_as_int(q2.z), gx, gy, mnx, mny, mxx, mxy);
-        const uint32_t tilepos = (by - mny) * (mxx - mnx) + (bx - mnx);
-        uint32_t row;
-        if (__float_as_uint(q3.w) == 0u) {
-            const unsigned long long mask = ((unsigned long long)__float_as_uint(q3.z) << 32) | __float_as_uint(q3.y);
-            if (!((mask >> tilepos) & 1ull)) continue;
-            row = __float_as_uint(q3.x) + (uint32_t)__popcll(mask & ((1ull << tilepos) - 1ull));
-        } else
-            row = __float_as_uint(q3.x) + tilepos;
-        const float z[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        gsr_row_store(grad_rows, row, z);
+    zero_rows();
+    if (GSR_LOG_PROFILE) {
+        GSR_PROF_MARK(4);
+        prof[0] = (unsigned long long)(clock64() - t_begin);
+        if (lane == 0)
+            for (int t = 0; t < 8; t++) atomicAdd(&g_blend_prof[t], prof[t]);
     }
 }
 
@@ -718,7 +748,7 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
 void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                 const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
                                 const uint32_t* order, float* grad_rows, float mean_list, const unsigned long long* blend_log,
-                                hipStream_t s)
+                                const uint32_t* quad_hi, hipStream_t s)
 {
     if (!gsr_variant("LPT", 1)) order = nullptr;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
@@ -731,10 +761,10 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
     if (blend_log) {  // the forward logged its blend decisions (render_forward.hip): the walk reads them instead of re-deriving them
         if (nq == 2)
             hipLaunchKernelGGL((render_backward_log_kernel<2>), dim3(gx * gy), dim3(128), (size_t)gsr_variant("BWD_PADLDS", 0), s, W, H, gx, gy, order, ranges,
-                               point_list, splat, bg, final_T, n_contrib, dL_dpix, blend_log, grad_rows);
+                               point_list, splat, bg, final_T, quad_hi, dL_dpix, blend_log, grad_rows);
         else
             hipLaunchKernelGGL((render_backward_log_kernel<1>), dim3(gx * gy), dim3(256), (size_t)gsr_variant("BWD_PADLDS", 0), s, W, H, gx, gy, order, ranges,
-                               point_list, splat, bg, final_T, n_contrib, dL_dpix, blend_log, grad_rows);
+                               point_list, splat, bg, final_T, quad_hi, dL_dpix, blend_log, grad_rows);
         return;
     }
     const bool fast = gsr_variant("BWD_FASTEXP", 1) != 0;
@@ -747,3 +777,12 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
 }
 
 int gsr_render_backward_ablate() { return GSR_ABLATE; }
+
+// copies and clears the phase profile of the log walk (all zero unless built with -DGSR_LOG_PROFILE=1)
+int gsr_blend_profile_fetch(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_blend_prof), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_blend_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return GSR_LOG_PROFILE;
+}

@@ -19,25 +19,36 @@ namespace {
 #ifndef GSR_FWD_LOG_ABLATE
 #define GSR_FWD_LOG_ABLATE 0
 #endif
+// Phase profile (make EXTRA=-DGSR_LOG_PROFILE=1, never in the shipped build): wave-cycles per phase of the quadrant walk, summed over all waves:
+// [0] whole wave, [1] staging loads + reach tests, [2] barriers + LDS writes, [3] walk (+ window stores), [4] prologue + epilogue
+#ifndef GSR_LOG_PROFILE
+#define GSR_LOG_PROFILE 0
+#endif
+__device__ unsigned long long g_fwd_prof[8];
+#define GSR_FPROF_MARK(slot) do { if (GSR_LOG_PROFILE) { const long long t_ = clock64(); fprof[slot] += (unsigned long long)(t_ - ft_last); ft_last = t_; } } while (0)
 #ifndef GSR_FWD_GROUP
 #define GSR_FWD_GROUP 4  // entries per turn of the walk (the all-pixels-done test runs once per turn)
 #endif
 
-// LOG (QUAD only): the blend log.  Every (list entry, 8x8 quadrant) visit of the walk leaves the 64-bit mask of the lanes (pixels) that
-// blended the entry -- the outcome of every decision of forward.cu:332-352 for 64 pixels -- at blend_log[4 * (list position) + quadrant],
-// zero when none did.  The backward (render_backward.hip, log walk) reads the masks instead of re-deriving them: no range test, no
-// threshold test, no alpha test, no n_contrib bookkeeping, and the decisions are the forward's by construction.  The masks live in
-// scalar registers (a ballot), so they are written with SCALAR stores (s_store_dwordx2, no VALU slot; tools/smem_probe.hip: gfx950
-// executes them, the scalar cache writes back dirty bytes, ~0.1 us per record with the chip full) and flushed by s_dcache_wb at the
-// end of the wave.  Slots of visits that did not happen (quadrant out of the splat's reach, or behind the wave's exit) are never written:
-// the backward recomputes the reach bit and knows the exit from n_contrib.
+// LOG (QUAD only): the blend log.  Every (list entry, 8x8 quadrant) visit of the walk that blends leaves the 64-bit mask of the lanes
+// (pixels) that blended the entry -- the outcome of every decision of forward.cu:332-352 for 64 pixels -- at
+// blend_log[gsr_blend_log_slot(list position, quadrant)].  The backward (render_backward.hip, log walk) reads the masks instead of re-deriving
+// them: no range test, no threshold test, no alpha test, no n_contrib bookkeeping, and the decisions are the forward's by construction.
+// How the masks get to memory (round 5, designs measured: profiles/README.md): a mask is a ballot, i.e. it lives in scalar registers.
+// Scalar stores (s_store_dwordx2) work on gfx950 and cost no VALU slot, but one per visit made the forward 18 % slower (the scalar cache
+// takes ~4 bytes per clock per CU, every store counts on lgkmcnt like the LDS operand reads, and its data registers must stay untouched
+// until it completes).  So a wave keeps the masks of the 64-entry window it is walking in a VGPR pair -- lane j holds the mask of the
+// window's entry j, written with v_writelane_b32 when a visit blends -- and stores the pair once per window, one coalesced 8-byte store
+// per lane; entries it did not visit, or that blended nowhere, read as zero.  Windows the wave never walks (behind its exit) are never
+// stored: the backward knows the exit from n_contrib.
 template <bool QUAD, bool LOG>
 __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, int gy, int wave8x8, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list,
                                                              const float* __restrict__ splat, const float* __restrict__ bg,
                                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                             float* __restrict__ out_color, unsigned long long* blend_log)
+                                                             float* __restrict__ out_color, unsigned long long* blend_log,
+                                                             uint32_t* __restrict__ quad_hi)
 {
     __shared__ float4 s_a[256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)];  // mx, my, conic.x, conic.y          (+4: padding entries for the unrolled walk)
     __shared__ float4 s_b[256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
@@ -63,6 +74,9 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     const int total = (int)(r1 - r0);
     const int rounds = (total + 255) / 256;
 
+    unsigned long long fprof[5] = {0, 0, 0, 0, 0};
+    long long ft_last = GSR_LOG_PROFILE ? clock64() : 0;
+    const long long ft_begin = ft_last;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
     // `done` is encoded in px: a finished (or outside) pixel is parked at x = PARKED, which drives its `power` to
@@ -75,15 +89,12 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
         s_a[256 + tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
         s_b[256 + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
     }
-    // LOG: the slot of (list position 0 of this tile, this wave's quadrant) -- gsr_blend_log_slot, common.h; entry j of round i lies
-    // 32 * (256 i + j) bytes further.  A padding entry of the unrolled walk writes to the tile's spare position (one behind its list).
+    // LOG: the masks of the window being walked (lane j: entry j of the window) and the slot of (list position `lane` of the tile, this
+    // wave's quadrant): the window starting at list position p stores at log_lane + 4 p
     const uint32_t wave_s = __builtin_amdgcn_readfirstlane((uint32_t)wave);
-    const unsigned long long* log_tile = LOG ? blend_log + gsr_blend_log_slot(r0, tile, wave_s) : nullptr;
-    const uint32_t log_spare = 32u * (uint32_t)total;
-    unsigned long long pend_m[GSR_FWD_GROUP];  // masks of the group walked last, stored during the next one
-    uint32_t pend_o[GSR_FWD_GROUP];
-#pragma unroll
-    for (int v = 0; v < GSR_FWD_GROUP; v++) { pend_m[v] = 0ull; pend_o[v] = log_spare; }
+    uint32_t log_lo = 0u, log_hi = 0u;
+    unsigned long long* log_lane = LOG ? blend_log + gsr_blend_log_slot(r0 + (uint32_t)lane, wave_s) : nullptr;
+    GSR_FPROF_MARK(4);
     for (int i = 0; QUAD && i < rounds; i++) {
         // QUAD: every staged entry is tested against the four 8x8 quadrants of the tile (gsr_quad_mask) and stays at its staged
         // position; a wave walks only the entries that can reach ITS block, picking them from the ballot masks with scalar bit
@@ -100,6 +111,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             if (wave8x8 == 2 && qm) qm = 15u;  // debugging aid (GSR_QUAD=2): every kept entry visits every wave
         }
         const unsigned long long b0 = __ballot(qm & 1u), b1 = __ballot(qm & 2u), b2 = __ballot(qm & 4u), b3 = __ballot(qm & 8u);
+        GSR_FPROF_MARK(1);
         __syncthreads();  // previous batch fully consumed
         if (lane == 0) { s_done[wave] = wave_done; s_qm[0][wave] = b0; s_qm[1][wave] = b1; s_qm[2][wave] = b2; s_qm[3][wave] = b3; }
         if (qm != 0u) {
@@ -110,6 +122,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             s_c[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
         }
         __syncthreads();
+        GSR_FPROF_MARK(2);
         // workgroup-wide early exit (forward.cu:301-304)
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
         if (wave_done) continue;
@@ -121,13 +134,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             while (m != 0ull) {
                 // the next (up to) four entries of this wave; missing ones are the padding entry
                 int jj[GSR_FWD_GROUP];
-                uint32_t lo[GSR_FWD_GROUP];  // LOG: where each visit's mask goes (byte offset from log_tile)
-                unsigned long long new_m[GSR_FWD_GROUP];
 #pragma unroll
                 for (int u = 0; u < GSR_FWD_GROUP; u++) {
                     const bool real = m != 0ull;
                     jj[u] = real ? 64 * w + (int)__builtin_ctzll(m) : 256 + u;
-                    if (LOG) lo[u] = real ? 32u * (uint32_t)(256 * i + jj[u]) : log_spare;
                     m &= m - 1ull;
                 }
 #pragma unroll
@@ -193,40 +203,26 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                   [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
                                 : [parked] "v"(PARKED), [md] "s"(m_done), [mb] "s"(blended), [cx] "v"(c.x), [cy] "v"(c.y), [cz] "v"(c.z),
                                   [al] "v"(alpha), [tT] "v"(test_T), [bw] "v"(b.w));
+                            // the entry's mask into lane (entry's index in the window) of the window's pair.  (A padding entry of the
+                            // unrolled walk never gets here: its threshold is +inf.)
+                            if (GSR_FWD_LOG_ABLATE != 2)
+                                asm volatile("s_mov_b32 m0, %4\n s_nop 0\n v_writelane_b32 %0, %2, m0\n v_writelane_b32 %1, %3, m0"  // (one SGPR + m0 per VALU)
+                                             : "+v"(log_lo), "+v"(log_hi)
+                                             : "s"((uint32_t)blended), "s"((uint32_t)(blended >> 32)), "s"((uint32_t)j & 63u)
+                                             : "m0");
                         }
-                        // the masks of this group are stored while the NEXT group computes (below): a scalar store counts on lgkmcnt like
-                        // an LDS read, so a store issued here would be waited for by the next entry's operand reads
-                        new_m[u] = blended;
                     }
-                    if (LOG && u == 0) {
-                        // the previous group's four masks (first turn: four zero masks to the spare slot)
-#pragma unroll
-                        for (int v = 0; v < GSR_FWD_GROUP; v++)
-                            if (GSR_FWD_LOG_ABLATE != 2) asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(pend_m[v]), "s"(log_tile), "s"(pend_o[v]) : "memory");
-                    }
-                    if (LOG && u == 1) {
-                        // A scalar store reads its data registers some time AFTER it issues (seen as a handful of wrong masks when the
-                        // allocator reused them at once): the eight data and four offset registers stay untouched until the stores have
-                        // completed.  Here the second entry's operands have just arrived from LDS, so the counter is (nearly) at zero anyway.
-                        static_assert(GSR_FWD_GROUP == 4, "keep-alive list below");
-                        asm volatile("s_waitcnt lgkmcnt(0) ; keepalive %0 %1 %2 %3 %4 %5 %6 %7 %8" ::"s"(pend_m[0]), "s"(pend_m[1]), "s"(pend_m[2]), "s"(pend_m[3]), "s"(pend_o[0]),
-                                     "s"(pend_o[1]), "s"(pend_o[2]), "s"(pend_o[3]), "s"(log_tile), "v"(power) : "memory");
-                    }
-                }
-                if (LOG) {
-#pragma unroll
-                    for (int v = 0; v < GSR_FWD_GROUP; v++) { pend_m[v] = new_m[v]; pend_o[v] = lo[v]; }
                 }
                 if (!gsr_any(px != PARKED)) { wave_done = true; break; }
             }
+            if (LOG && GSR_FWD_LOG_ABLATE != 1) {
+                // the window's masks (whatever the wave walked of it): list positions 256 i + 64 w + lane, as far as the list goes
+                const uint32_t p0 = (uint32_t)(256 * i + 64 * w);
+                if (p0 + (uint32_t)lane < (uint32_t)total) log_lane[4 * (size_t)p0] = ((unsigned long long)log_hi << 32) | log_lo;
+                log_lo = 0u; log_hi = 0u;
+            }
         }
-    }
-    if (LOG && total > 0) {  // the last group's masks (an empty tile has range (0, 0): its "spare slot" would be somebody's list position)
-#pragma unroll
-        for (int v = 0; v < GSR_FWD_GROUP; v++)
-            if (GSR_FWD_LOG_ABLATE != 2) asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(pend_m[v]), "s"(log_tile), "s"(pend_o[v]) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(pend_m[0]), "s"(pend_m[1]), "s"(pend_m[2]), "s"(pend_m[3]), "s"(pend_o[0]), "s"(pend_o[1]),
-                     "s"(pend_o[2]), "s"(pend_o[3]), "s"(log_tile) : "memory");
+        GSR_FPROF_MARK(3);
     }
     for (int i = 0; !QUAD && i < rounds; i++) {
         // gather this batch's records and decide, per entry, whether the tile can see it at all
@@ -311,16 +307,36 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
         out_color[plane + pix_id] = C1 + T * bg[1];
         out_color[2 * plane + pix_id] = C2 + T * bg[2];
     }
-    if (LOG) asm volatile("s_waitcnt lgkmcnt(0)\n s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");  // the scalar stores leave the scalar cache
+    if (LOG) {
+        // the quadrant's largest n_contrib = how far its log goes (the backward stages nothing of this quadrant behind it)
+        uint32_t m = last_contributor;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+        if (lane == 0) quad_hi[4 * tile + wave_s] = m;
+    }
+    if (GSR_LOG_PROFILE && QUAD) {
+        GSR_FPROF_MARK(4);
+        fprof[0] = (unsigned long long)(clock64() - ft_begin);
+        if (lane == 0)
+            for (int t = 0; t < 5; t++) atomicAdd(&g_fwd_prof[t], fprof[t]);
+    }
 }
 
 }  // namespace
 
 // blend_log: the R-sized mask array of the binning buffer (BinLayout::blend_log), or NULL (no log: the backward then re-derives every
 // decision).  Written only by the quadrant walk (GSR_QUAD=1, GSR_WAVE8X8=1, the default): gsr_blend_log_enabled (api.hip) says whether it is.
+int gsr_forward_profile_fetch(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fwd_prof), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return GSR_LOG_PROFILE;
+}
+
 void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* splat,
                                const float* bg, float* final_T, uint32_t* n_contrib, float* out_color, const uint32_t* order,
-                               unsigned long long* blend_log, hipStream_t s)
+                               unsigned long long* blend_log, uint32_t* quad_hi, hipStream_t s)
 {
     if (!gsr_variant("LPT", 1)) order = nullptr;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
@@ -329,11 +345,11 @@ void gsr_launch_render_forward(int W, int H, const uint32_t* ranges, const uint3
         const int mode = gsr_variant("QUAD", 1) == 2 ? 2 : 1;
         if (blend_log && mode == 1)
             hipLaunchKernelGGL((render_forward_kernel<true, true>), dim3(gx * gy), dim3(256), (size_t)gsr_variant("FWD_PADLDS", 0), s, W, H, gx, gy, mode, order, ranges,
-                               point_list, splat, bg, final_T, n_contrib, out_color, blend_log);
+                               point_list, splat, bg, final_T, n_contrib, out_color, blend_log, quad_hi);
         else
             hipLaunchKernelGGL((render_forward_kernel<true, false>), dim3(gx * gy), dim3(256), (size_t)gsr_variant("FWD_PADLDS", 0), s, W, H, gx, gy, mode, order, ranges,
-                               point_list, splat, bg, final_T, n_contrib, out_color, (unsigned long long*)nullptr);
+                               point_list, splat, bg, final_T, n_contrib, out_color, (unsigned long long*)nullptr, (uint32_t*)nullptr);
     } else
         hipLaunchKernelGGL((render_forward_kernel<false, false>), dim3(gx * gy), dim3(256), 0, s, W, H, gx, gy, wave8x8, order, ranges, point_list, splat, bg,
-                           final_T, n_contrib, out_color, (unsigned long long*)nullptr);
+                           final_T, n_contrib, out_color, (unsigned long long*)nullptr, (uint32_t*)nullptr);
 }

@@ -234,6 +234,9 @@ int gsr_debug_capture_sums(float* sums);
 /* Measurement hook (bench.py's roofline_knn): while `counter` (a device uint64, zeroed by the caller) is non-NULL, gsr_knn_mean_dist2
  * adds to it the number of candidate distances its queries evaluate.  NULL switches it off. */
 int gsr_debug_knn_counter(uint64_t* counter);
+/* wave-cycle sums per phase of the blend kernels since the last call: [0..7] backward log walk, [8..15] forward quadrant walk (a library built
+ * with -DGSR_LOG_PROFILE=1; else zeros): returns 1 / 0 */
+int gsr_debug_blend_profile(uint64_t* counters16);
 
 /* What this binary was built with: "abi=<n> ablate=<GSR_ABLATE> bin_ablate=<GSR_BIN_ABLATE> extra=[<make EXTRA=...>]".  The two
  * ablation macros are timing experiments that produce wrong results on purpose; a shipped library reports 0 for both and an
