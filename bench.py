@@ -638,8 +638,14 @@ def main():
     # the opening barrier, its start stamp, its workload (V / R / listed instances, means over the cameras the timed steps used) and
     # the dominant stage's average -- all-gathered so that rank 0's line can say WHICH rank set the MAX and why.
     used_local = [stats[(args.warmup + i) % len(stats)] for i in range(args.steps)]
-    dom_ms, dom_n = (timed.get(dominant) or stage.get(dominant) or (0.0, 0))
-    bwd_ms, bwd_n = (timed.get("render_backward") or stage.get("render_backward") or (0.0, 0))
+    def _stage_avg(name):  # as measured inside the timed region if the stage carried events there, else in the untimed all-stages pass
+        for src in (timed, stage):
+            ms, n = src.get(name, (0.0, 0))
+            if n > 0:
+                return ms, n
+        return 0.0, 0
+    dom_ms, dom_n = _stage_avg(dominant)
+    bwd_ms, bwd_n = _stage_avg("render_backward")
     mine = [elapsed, opening_barrier_ms, t0_wall, float(np.mean([u["V"] for u in used_local])), float(np.mean([u["R"] for u in used_local])),
             float(np.mean([u["listed"] for u in used_local])), float(np.mean([u["tile_mean"] for u in used_local])),
             float(max(u["tile_max"] for u in used_local)), dom_ms / max(dom_n, 1), bwd_ms / max(bwd_n, 1), cold_ms,
