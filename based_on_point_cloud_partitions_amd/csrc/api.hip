@@ -225,9 +225,21 @@ static bool gsr_variant_store(const char* name, int value)
 // those instances lie outside the alpha >= 1/255 ellipse (gsr_reach_mask) and cannot contribute to any pixel.  Leaving them out
 // changes no pixel and no gradient; GSR_CULL=0 keeps the reference's lists bit for bit (sort keys, point_list, ranges, n_contrib).
 bool gsr_cull_enabled() { return gsr_variant("CULL", 1) && gsr_variant("BIN", 1); }
-// The blend log (render_forward.hip) is written by the quadrant walk of the forward only; forward and backward of one frame must see the
-// same answer (the switches are read at launch time: change them between frames, not between a forward and its backward).
-bool gsr_blend_log_enabled() { return gsr_variant("BLEND_LOG", 1) && gsr_variant("QUAD", 1) == 1 && gsr_variant("WAVE8X8", 1) != 0; }
+// The blend log (render_forward.hip) is written by the quadrant walk of the forward only.  GSR_BLEND_LOG: 0 never, 2 always, 1 (default) when
+// the mean length of the reference's tile lists is below GSR_BLEND_LOG_LIST (700): measured (round 5, profiles/README.md) the log takes
+// 3-17 % off the step where lists are short (500k Gaussians at 1080p, mean 467: 0.695 -> 0.681 ms; 10k at 256x256: 0.160 -> 0.149;
+// 150k at 640x360: 0.419 -> 0.391) and costs 1-1.5 % where they are long (1M, mean 930: 0.960 -> 0.971; 2M, 1866: 1.629 -> 1.649 -- the
+// forward pays 6 % for writing it and the four-waves-per-tile backward of those scenes gains nothing from reading it).  Forward and backward
+// of one frame get the same answer because both ask with the frame's own R and image size; the switches are read at launch time, so
+// change them between frames, not between a forward and its backward.
+bool gsr_blend_log_for(int64_t R, int W, int H)
+{
+    const int mode = gsr_variant("BLEND_LOG", 1);
+    if (mode == 0 || R <= 0 || gsr_variant("QUAD", 1) != 1 || gsr_variant("WAVE8X8", 1) == 0) return false;
+    if (mode == 2) return true;
+    const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+    return (float)R / (float)(gx * gy) < (float)gsr_variant("BLEND_LOG_LIST", 700);
+}
 
 extern "C" {
 
@@ -484,7 +496,7 @@ static int forward_render_impl(int P, int64_t R, int W, int H, const float* back
     {
         StageTimer t(GSR_STAGE_RENDER_FWD, s);
         const uint32_t* order = (R > 0 && gsr_variant("BIN", 1)) ? (const uint32_t*)(b + B.order) : nullptr;
-        unsigned long long* blend_log = (R > 0 && gsr_blend_log_enabled()) ? (unsigned long long*)(b + B.blend_log) : nullptr;
+        unsigned long long* blend_log = gsr_blend_log_for(R, W, H) ? (unsigned long long*)(b + B.blend_log) : nullptr;
         gsr_launch_render_forward(W, H, ranges, point_list, (const float*)(g + G.splat), background, (float*)(im + I.final_T),
                                   (uint32_t*)(im + I.n_contrib), out_color, order, blend_log, (uint32_t*)(im + I.quad_hi), s);
     }
@@ -605,7 +617,7 @@ static int run_backward(GaussBackwardArgs a, int64_t R, const float* background,
                                    (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), dL_dpix,
                                    gsr_variant("BIN", 1) ? (const uint32_t*)(b + B.order) : nullptr, (float*)scratch,
                                    (float)R / (float)(gx * gy),
-                                   gsr_blend_log_enabled() ? (const unsigned long long*)(b + B.blend_log) : nullptr,
+                                   gsr_blend_log_for(R, W, H) ? (const unsigned long long*)(b + B.blend_log) : nullptr,
                                    (const uint32_t*)(im + I.quad_hi), s);
     }
     a.cov3D_in = cov3D_precomp ? cov3D_precomp : (const float*)(g + G.cov3D);

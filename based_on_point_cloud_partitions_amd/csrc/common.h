@@ -276,7 +276,7 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
                                 const uint32_t* quad_hi, hipStream_t s);
 int gsr_blend_profile_fetch(unsigned long long* out8);
 int gsr_forward_profile_fetch(unsigned long long* out8);  // render_forward.hip: the same for the forward's quadrant walk  // render_backward.hip: phase profile of the log walk (profiling builds)
-bool gsr_blend_log_enabled();                 // the forward's quadrant walk logs its blend decisions for the backward (render_forward.hip)
+bool gsr_blend_log_for(int64_t R, int W, int H);  // does this frame's forward log its blend decisions for the backward? (api.hip)
 int gsr_variant(const char* name, int dflt);  // experiment switch read from the environment (GSR_<name>)
 bool gsr_cull_enabled();                      // tile lists without the instances the splat's alpha >= 1/255 ellipse cannot reach
 struct GaussBackwardArgs {

@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
 }  // namespace
 
 // blend_log: the R-sized mask array of the binning buffer (BinLayout::blend_log), or NULL (no log: the backward then re-derives every
-// decision).  Written only by the quadrant walk (GSR_QUAD=1, GSR_WAVE8X8=1, the default): gsr_blend_log_enabled (api.hip) says whether it is.
+// decision).  Written only by the quadrant walk (GSR_QUAD=1, GSR_WAVE8X8=1, the default): gsr_blend_log_for (api.hip) says whether it is.
 int gsr_forward_profile_fetch(unsigned long long* out8)
 {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
