@@ -71,7 +71,13 @@ from based_on_point_cloud_partitions_amd import GaussianRasterizationSettings, G
 from based_on_point_cloud_partitions_amd import synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PLAIN_CYCLES = 2.4  # SIMD cycles per plain wave64 VOP2/VOP3 instruction with 4-8 waves per SIMD (profiles/r01_valu_cost.txt)
+VALU_PLAIN_CYCLES = 2.4  # SIMD cycles per plain wave64 fp32 add / mul / fma with 4-8 waves per SIMD, at a nominal 2.4 GHz (profiles/r01_valu_cost.txt)
+VALU_GUIDE_CYCLES = 2.0  # MI355X_MICROARCH.md: wave64 v_fma_f32 = 2 cycles -> 1024 SIMDs x 2.4 GHz / 2 = 1,229 G wave-instructions/s
+# Round 5 (tools/salu_probe.hip, profiles/r05_salu_probe.txt), ns per wave-instruction per SIMD with 8 waves resident: fp32 add / mul / fma 1.06;
+# EVERY other VALU class measured (int32, compares, selects, SGPR operands, readlane / writelane, DPP) 1.75-1.9; every SALU instruction 1.75
+# (not-taken branch ~0.4); v_exp / v_rcp / permlane swaps ~3.6 (r01).  SALU and VALU issue side by side (32 v_fma + 32 s_and per wave take
+# the SALU time + 10 %), so a kernel has TWO issue budgets: its VALU time and its SALU time.
+NS_SALU = 1.75
 VALU_BOUND = ("render_backward", "render_forward")  # the VALU-issue-bound kernels
 
 
@@ -80,12 +86,13 @@ def price_list_cycles(v):
     measured price list of gfx950 (tools/valu_cost.hip): the counted plain classes (f32 add / mul / fma, int32) 2.4 cycles, transcendentals
     (v_exp, v_rcp) 8.5, everything the class counters do not name -- compares, selects, lane reads, permlane swaps, converts, moves --
     4.3.  DPP-modified adds are counted as plain adds and some of the unnamed instructions are plain moves, so this is an estimate of the
-    kernel's issue time, not a bound; None when the class counters are not on file."""
+    kernel's issue time, not a bound; None when the class counters are not on file.  (Round 5: int32 moved from the plain to the 4.3-cycle
+    class after tools/salu_probe.hip measured v_add_u32 / v_lshlrev_b32 at 1.77 ns.)"""
     need = ("sq_insts_valu", "sq_insts_valu_add_f32", "sq_insts_valu_mul_f32", "sq_insts_valu_fma_f32", "sq_insts_valu_int32",
             "sq_insts_valu_trans_f32")
     if not all(k in v for k in need):
         return None
-    plain = v["sq_insts_valu_add_f32"] + v["sq_insts_valu_mul_f32"] + v["sq_insts_valu_fma_f32"] + v["sq_insts_valu_int32"]
+    plain = v["sq_insts_valu_add_f32"] + v["sq_insts_valu_mul_f32"] + v["sq_insts_valu_fma_f32"]  # (round 5: int32 is NOT plain: 1.77 ns)
     trans = v["sq_insts_valu_trans_f32"]
     other = max(v["sq_insts_valu"] - plain - trans, 0.0)
     return (2.4 * plain + 8.5 * trans + 4.3 * other) / v["sq_insts_valu"]
@@ -800,18 +807,25 @@ def main():
                    if hbm["traffic"] is not None else None)
             if d["kernel"] in VALU_BOUND and "valu_insts" in d:
                 # The blend kernels are pair loops limited by VALU instruction issue, not by HBM: the roofline they are
-                # priced against is the chip's VALU issue rate.  `peak` = 1024 SIMDs x 2.4 GHz / 2.4 cycles per plain wave64 VOP
-                # (tools/valu_cost.hip, profiles/r01_valu_cost.txt), `achieved` = VALU wave-instructions retired per second (PMC count
-                # / this run's average launch duration): `frac` is the share of the kernel's SIMD cycles that issuing its VALU
-                # instructions at the PLAIN price needs (a floor).  `frac_price_list` prices the kernel's measured instruction mix
-                # (price_list_cycles above).
+                # priced against is the chip's VALU issue rate.  `peak` = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 v_fma_f32
+                # (MI355X_MICROARCH.md), `achieved` = VALU wave-instructions retired per second (PMC count / this run's average launch
+                # duration).  `peak_measured_plain_fma` is what a loop of independent v_fma_f32 reaches here (2.4 cycles, tools/valu_cost.hip);
+                # `frac_price_list` prices the kernel's measured instruction mix (price_list_cycles above): the share of the kernel's
+                # SIMD time its VALU instructions need at their measured issue costs.  `salu` is the scalar pipe's share.
                 rate = d["valu_insts"] / (d["avg_ms"] * 1e-3) / 1e9
-                peak = 1024 * 2.4 / VALU_PLAIN_CYCLES
+                peak = 1024 * 2.4 / VALU_GUIDE_CYCLES        # the guide's figure (wave64 v_fma_f32 = 2 cycles)
+                peak_meas = 1024 * 2.4 / VALU_PLAIN_CYCLES   # what a loop of independent v_fma_f32 reaches on this chip (2.4 cycles)
                 pl = d.get("price_list_cycles_per_valu_inst")
+                pv = pmc.get(d["kernel"], {})
+                scalar = pv.get("sq_insts_salu", 0.0) + pv.get("sq_insts_branch", 0.0) + pv.get("sq_insts_smem", 0.0)
                 roofline = {"kernel": d["kernel"], "bound": "valu_issue", "achieved": round(rate, 1), "peak": round(peak, 1),
                             "unit": "G wave-instr/s", "frac": round(rate / peak, 4),
-                            "frac_price_list": round(rate / peak * pl / VALU_PLAIN_CYCLES, 4) if pl else None,
+                            "peak_measured_plain_fma": round(peak_meas, 1), "frac_of_measured_plain_peak": round(rate / peak_meas, 4),
+                            "frac_price_list": round(rate / peak_meas * pl / VALU_PLAIN_CYCLES, 4) if pl else None,
                             "mean_cycles_per_inst_price_list": pl,
+                            # the second issue budget: scalar instructions (SALU + branches + scalar memory) at the measured 1.75 ns each
+                            "salu": ({"insts": int(scalar), "ns_per_inst": NS_SALU,
+                                      "pipe_frac": round(scalar * NS_SALU * 1e-9 / 1024 / (d["avg_ms"] * 1e-3), 4)} if scalar else None),
                             "valu_insts": d["valu_insts"], "simd_cycles_per_valu_inst": d["simd_cycles_per_valu_inst"],
                             "traffic": hbm["traffic"], "traffic_source": src, "avg_ms": d["avg_ms"], "hbm": hbm,
                             "note": "dominant kernel by time; VALU-issue-bound pair loop -- its HBM figures are under `hbm` (low by "

@@ -21,6 +21,7 @@ STAGE = {
     "tile_scatter_kernel": "radix_sort", "tile_sort_small_kernel": "radix_sort", "tile_sort_large_kernel": "radix_sort", "global_hist_kernel": "radix_sort",
     "block_hist_kernel": "radix_sort", "bin_scan_kernel": "radix_sort", "scatter_kernel": "radix_sort",
     "tile_ranges_kernel": "tile_ranges", "render_forward_kernel": "render_forward", "render_backward_kernel": "render_backward",
+    "render_backward_log_kernel": "render_backward",
     "gaussian_backward_kernel": "gaussian_backward",
 }
 
@@ -56,7 +57,7 @@ def main(d, out):
     sqp = f"{d}/sq_counter_collection.csv"
     sq = {c: load(sqp, c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES")} if os.path.exists(sqp) else {}
     # instruction classes (separate passes sq3 / sq4 of tools/r4_collect.sh): what bench.py prices the VALU-bound kernels with
-    for extra, names in (("sq3", ("SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT")),
+    for extra, names in (("sq3", ("SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM")),
                          ("sq4", ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_INT32"))):
         ep = f"{d}/{extra}_counter_collection.csv"
         if os.path.exists(ep):
@@ -66,7 +67,8 @@ def main(d, out):
     if os.path.exists(sj):
         per_kernel = json.load(open(sj))
         for c in ("SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
-                  "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
+                  "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES",
+                  "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
             if c not in sq or not sq[c]:
                 sq[c] = {k.split("<")[0]: v[c] for k, v in per_kernel.items() if c in v}
     for c, per in sq.items():
