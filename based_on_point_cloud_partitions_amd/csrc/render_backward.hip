@@ -47,8 +47,9 @@ namespace {
 // Measured alternatives (round 3, cfg2 two waves per tile / 2M Gaussians four waves per tile, ms): cross-row levels FIRST with pair-wise
 // permlane swaps (8 swaps + 7 DPP, no select at all): 0.349 / 0.668 against 0.338 / 0.637 -- a swap costs far more than its 8.5 cycles
 // back to back suggest; cross-row levels through ds_bpermute_b32: 0.347 / 0.676 (the LDS round trip lengthens every entry's chain).
-__device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
-                                                   float v8, unsigned long long m0, unsigned long long m2)
+// wave_sum9_rows: the in-row levels only -- lane l of EVERY row then holds its row's partial of the value the lane keeps.
+__device__ __forceinline__ float wave_sum9_rows(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                                float v8, unsigned long long m0, unsigned long long m2)
 {
     float t0;
     asm volatile(
@@ -82,6 +83,12 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
         "v_cndmask_b32 %0, %0, %8, %11\n"
         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "=&v"(t0)
         : "s"(m0), "s"(m2));
+    return v0;
+}
+__device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                                   float v8, unsigned long long m0, unsigned long long m2)
+{
+    v0 = wave_sum9_rows(v0, v1, v2, v3, v4, v5, v6, v7, v8, m0, m2);
     // levels 5, 6: lane-wise across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap
     {
         const uint32_t u = __float_as_uint(v0);
@@ -98,6 +105,21 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
 // the lanes that hold a total after wave_sum9_scatter, and which
 __device__ __forceinline__ bool gsr_sum9_writer(int lane) { return lane < 16 && ((lane & 2) == 0 || lane == 2); }
 __device__ __forceinline__ int gsr_sum9_slot(int lane) { return lane == 2 ? 8 : (lane & 1) + 2 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1); }
+
+// The two cross-row levels on the MATRIX core (round 5): v_mfma_f32_16x16x4_f32 with A = the row partials (lane l supplies A[l % 16][l / 16])
+// and B = ones gives D[i][j] = sum over the four rows of position i, for every j -- the sum the two permlane swaps + two adds + two
+// copies (~27 VALU cycles) formed, for one VALU issue slot; the 8 passes run beside the VALU.  Lane (g = l / 16, any j) then holds positions
+// 4g .. 4g+3 in its four result registers: value 0, 1, 8 in registers 0, 1, 2 of row 0, values 4, 5 / 2, 3 / 6, 7 in registers 0, 1 of rows
+// 1 / 2 / 3 (the positions wave_sum9_rows leaves them at).  Lanes 0, 16, 32, 48 add registers 0 and 1 to the entry's LDS sums, lane 0 also
+// register 2: three LDS atomics of 4 + 4 + 1 lanes instead of one of 9.  The sum of four fp32 terms in the core's fixed order: deterministic.
+// MEASURED (cfg2, one call, three alternations): 8 % fewer VALU instructions (178.6 M -> 164.9 M) and the kernel 1.7 % SLOWER (0.2960 vs
+// 0.2911 ms): the wave waits ~17 cycles on the matrix core per reduction, and it is the length of a wave's own chain, not the VALU issue
+// count, that the kernel is short of.  Parity-green; off by default (make EXTRA=-DGSR_BWD_MFMA=1).
+#ifndef GSR_BWD_MFMA
+#define GSR_BWD_MFMA 0
+#endif
+typedef float gsr_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int gsr_sum9_mfma_slot0(int lane) { const int g = lane >> 4; return g == 0 ? 0 : g == 1 ? 4 : g == 2 ? 2 : 6; }
 
 constexpr int NV = 9;  // partial sums per list entry
 constexpr uint32_t GSR_NO_ROW = 0x0FFFFFFFu;  // 28 bits of gradient-row index (the host refuses more instances), 4 of quadrant mask
@@ -539,6 +561,8 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
     const bool writer = gsr_sum9_writer(lane);
     const int my_slot = gsr_sum9_slot(lane);
     float* my_acc = s_acc + (NQ == 2 ? 0 : (wave >> 1) * BATCH * NV);
+    float* acc_lane = my_acc + gsr_sum9_mfma_slot0(lane);  // GSR_BWD_MFMA: where this lane's result registers 0, 1 (+ 8: register 2 of lane 0) go
+    const bool w4 = (lane & 15) == 0, w1 = lane == 0;
     const int rounds = (int)((hi + BATCH - 1) / BATCH);
     // the masks of (list position 0 of the tile, this wave's first quadrant); position k lies 4 k words further
     const unsigned long long* logw = blend_log + gsr_blend_log_slot(r0, (uint32_t)q_first);
@@ -674,8 +698,22 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                 auto reduce = [&](float sw, float swx, float sxx, float c0, float c1, float c2) __attribute__((always_inline)) {
                     // the lane's pixels share dy: the y moments of their sum are products of the x moments with dy
                     const float swy = sw * dy;
-                    const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M2);
-                    if (writer) atomicAdd(&my_acc[jcur * NV + my_slot], tot);  // LDS
+                    if (GSR_BWD_MFMA) {
+                        const float rows = wave_sum9_rows(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M2);
+                        // (as asm: the builtin let the register allocator put the result tuple over the A operand -- v_mfma v[10:13], v11,
+                        // v48, 0 -- and the sums came out wrong; "=&v" keeps the four result registers apart from both sources.  The
+                        // wait states before the result may be read -- 8 passes -- are in the block: the compiler knows nothing of it.  And
+                        // the s_nop in FRONT: the A operand was written by the asm block above, invisible to the hazard recognizer; without
+                        // it the value parked last -- the ninth -- arrived stale.)
+                        gsr_f4v d;
+                        asm volatile("s_nop 4\n v_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n s_nop 7\n s_nop 3" : "=&v"(d) : "v"(rows), "v"(1.0f));
+                        float* o = acc_lane + jcur * NV;
+                        if (w4) { atomicAdd(o, d[0]); atomicAdd(o + 1, d[1]); }  // LDS
+                        if (w1) atomicAdd(o + 8, d[2]);
+                    } else {
+                        const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M2);
+                        if (writer) atomicAdd(&my_acc[jcur * NV + my_slot], tot);  // LDS
+                    }
                 };
                 // Each case is ONE straight-line block (two quadrants: their two chains -- sub, 6 mul/fma, exp, select, rcp, 10 mul/fma --
                 // are independent and interleave) and ends in its own copy of the reduction: nothing is merged behind the branches.
