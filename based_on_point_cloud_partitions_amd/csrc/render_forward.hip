@@ -15,7 +15,7 @@
 namespace {
 
 // Timing ablations of the blend log (results WRONG on purpose, never defined in the shipped build): -DGSR_FWD_LOG_ABLATE=n
-//   1: the stores without the mask (a constant is stored)   2: the mask without the stores
+//   1: no window stores (the masks are collected, not written)   2: no v_writelane (zeros are written)
 #ifndef GSR_FWD_LOG_ABLATE
 #define GSR_FWD_LOG_ABLATE 0
 #endif
