@@ -102,7 +102,7 @@ def main():
             print(f"{seed - first + 1} scenes, {len(out['failed'])} failed, {time.time() - t0:.0f} s", flush=True)
     out["seconds"] = round(time.time() - t0, 1)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r4_fuzz.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", os.environ.get("GSR_FUZZ_OUT", "r4_fuzz.json")), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "failed"}), "failures:", len(out["failed"]))
     for fl in out["failed"][:5]:
