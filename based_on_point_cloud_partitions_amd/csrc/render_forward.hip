@@ -176,6 +176,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                         // VALU slot, and the blend itself runs under EXEC = that mask (one asm block: the compiler cannot express "these
                         // lanes" from a scalar mask without rebuilding it per lane).  alpha / test_T are evaluated by all lanes; a lane
                         // outside the masks keeps nothing of them.  Same arithmetic per blending lane as the nested form: bit-identical.
+                        // (The block leaves EXEC = all ones: every lane of the 256-thread workgroup is active here -- the walk is under
+                        // wave-uniform control flow from the kernel's entry, finished and outside pixels are parked, not masked off.)
                         unsigned long long blended = 0ull;
                         const unsigned long long m_maybe = __builtin_amdgcn_ballot_w64(maybe);
                         if (m_maybe != 0ull) {  // wave-uniform
@@ -206,6 +208,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                             // the entry's mask into lane (entry's index in the window) of the window's pair.  (A padding entry of the
                             // unrolled walk never gets here: its threshold is +inf.)
                             if (GSR_FWD_LOG_ABLATE != 2)
+                                // (M0 is on the clobber list although the compiler warns that it "may not preserve" reserved registers: on gfx9 it
+                                // loads M0 right in front of each instruction that reads it and keeps nothing there across other code)
                                 asm volatile("s_mov_b32 m0, %4\n s_nop 0\n v_writelane_b32 %0, %2, m0\n v_writelane_b32 %1, %3, m0"  // (one SGPR + m0 per VALU)
                                              : "+v"(log_lo), "+v"(log_hi)
                                              : "s"((uint32_t)blended), "s"((uint32_t)(blended >> 32)), "s"((uint32_t)j & 63u)
