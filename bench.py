@@ -120,7 +120,7 @@ def per_rank_report(rows, steps, dominant):
     more work (V, R, listed instances) or just ran slower (the dominant stage's own average)."""
     keys = ("elapsed_s", "opening_barrier_wait_ms", "t0_wall", "V_mean", "R_mean", "instances_listed_mean", "tile_list_mean",
             "tile_list_max", "dominant_stage_avg_ms", "render_backward_avg_ms", "ms_per_step_cold", "closing_barrier_wait_ms",
-            "spinup_last_batch_ms_per_step", "device_index")
+            "spinup_last_batch_ms_per_step", "device_index", "dominant_stage_index")
     t_first = min(r[2] for r in rows)
     per = []
     for i, r in enumerate(rows):
@@ -130,7 +130,9 @@ def per_rank_report(rows, steps, dominant):
                     "start_offset_ms": round(1e3 * (d["t0_wall"] - t_first), 3), "closing_barrier_wait_ms": round(d["closing_barrier_wait_ms"], 3),
                     "V_mean": round(d["V_mean"], 1), "R_mean": round(d["R_mean"], 1), "instances_listed_mean": round(d["instances_listed_mean"], 1),
                     "tile_list_mean": round(d["tile_list_mean"], 1), "tile_list_max": int(d["tile_list_max"]),
-                    "dominant_stage": dominant, "dominant_stage_avg_ms": round(d["dominant_stage_avg_ms"], 4),
+                    # (every rank picks its own dominant stage from its own warm-up: the one it carried events around in the timed region)
+                    "dominant_stage": (_lib.STAGES[int(d["dominant_stage_index"])] if "dominant_stage_index" in d else dominant),
+                    "dominant_stage_avg_ms": round(d["dominant_stage_avg_ms"], 4),
                     "render_backward_avg_ms": round(d["render_backward_avg_ms"], 4), "ms_per_step_cold": round(d["ms_per_step_cold"], 4),
                     "spinup_last_batch_ms_per_step": round(d["spinup_last_batch_ms_per_step"], 4)})
     ms = [p_["ms_per_step"] for p_ in per]
@@ -656,7 +658,8 @@ def main():
     mine = [elapsed, opening_barrier_ms, t0_wall, float(np.mean([u["V"] for u in used_local])), float(np.mean([u["R"] for u in used_local])),
             float(np.mean([u["listed"] for u in used_local])), float(np.mean([u["tile_mean"] for u in used_local])),
             float(max(u["tile_max"] for u in used_local)), dom_ms / max(dom_n, 1), bwd_ms / max(bwd_n, 1), cold_ms,
-            1e3 * (elapsed_incl_barrier - elapsed), float(spinup["last_batch_ms_per_step"]) if spinup else 0.0, float(dev.index or 0)]
+            1e3 * (elapsed_incl_barrier - elapsed), float(spinup["last_batch_ms_per_step"]) if spinup else 0.0, float(dev.index or 0),
+            float(_lib.STAGES.index(dominant))]
     all_ranks = [mine]
     if dist is not None:
         cdev = dev if dist.get_backend() == "nccl" else "cpu"

@@ -256,15 +256,19 @@ def test_bench_per_rank_report_names_the_slowest_rank():
     from the all-gathered rows rank 0 derives who set the MAX, the start skew and whether that rank had more work."""
     import bench
 
-    rows = [[0.0200, 0.10, 100.0000, 5e5, 3.70e6, 2.30e6, 450, 2000, 0.32, 0.32, 0.70, 0.05, 0.69, 0],
-            [0.0230, 0.30, 100.0004, 5e5, 3.90e6, 2.50e6, 470, 2100, 0.36, 0.36, 0.75, 0.01, 0.70, 1],
-            [0.0190, 0.00, 100.0001, 5e5, 3.60e6, 2.20e6, 440, 1900, 0.31, 0.31, 0.69, 0.09, 0.68, 2]]
+    from based_on_point_cloud_partitions_amd import _lib
+
+    rb, rf = float(_lib.STAGES.index("render_backward")), float(_lib.STAGES.index("render_forward"))
+    rows = [[0.0200, 0.10, 100.0000, 5e5, 3.70e6, 2.30e6, 450, 2000, 0.32, 0.32, 0.70, 0.05, 0.69, 0, rb],
+            [0.0230, 0.30, 100.0004, 5e5, 3.90e6, 2.50e6, 470, 2100, 0.36, 0.36, 0.75, 0.01, 0.70, 1, rb],
+            [0.0190, 0.00, 100.0001, 5e5, 3.60e6, 2.20e6, 440, 1900, 0.18, 0.31, 0.69, 0.09, 0.68, 2, rf]]
     r = bench.per_rank_report(rows, 20, "render_backward")
     assert r["slowest_rank"] == 1 and r["fastest_rank"] == 2 and abs(r["skew_ms"] - 0.4) < 1e-6
     assert [p["rank"] for p in r["per_rank"]] == [0, 1, 2] and r["per_rank"][1]["ms_per_step"] == 1.15
     assert r["per_rank"][2]["start_offset_ms"] == 0.1 and r["per_rank"][0]["start_offset_ms"] == 0.0
     assert abs(r["slowest_vs_fastest"]["instances_listed"] - 2.5 / 2.2) < 1e-3
     assert abs(r["sum_of_rank_rates_it_per_s"] - (1000.0 + 20 / 0.023 + 20 / 0.019)) < 0.05
+    assert [p["dominant_stage"] for p in r["per_rank"]] == ["render_backward", "render_backward", "render_forward"]
 
 
 def test_bench_partitions_fill_the_single_gpu_scene_volume():
