@@ -119,7 +119,9 @@ __device__ __forceinline__ int gsr_sum9_slot(int lane) { return lane == 2 ? 8 : 
 // register 2: three LDS atomics of 4 + 4 + 1 lanes instead of one of 9.  The sum of four fp32 terms in the core's fixed order: deterministic.
 // MEASURED (cfg2, one call, three alternations): 8 % fewer VALU instructions (178.6 M -> 164.9 M) and the kernel 1.7 % SLOWER (0.2960 vs
 // 0.2911 ms): the wave waits ~17 cycles on the matrix core per reduction, and it is the length of a wave's own chain, not the VALU issue
-// count, that the kernel is short of.  Parity-green; off by default (make EXTRA=-DGSR_BWD_MFMA=1).
+// count, that the kernel is short of.  With the next entry's operand requests between the MFMA and the first read of its result instead
+// of the s_nops: 0.3135 ms -- the matrix core does not run beside the VALU here, an 8-pass MFMA costs the SIMD ~27 cycles of issue.
+// Parity-green; off by default (make EXTRA=-DGSR_BWD_MFMA=1).
 #ifndef GSR_BWD_MFMA
 #define GSR_BWD_MFMA 0
 #endif
