@@ -606,8 +606,14 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                 }
             }
             if (keep) {
-                qm = gsr_quad_mask(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0);
-                qm &= (k < h0 ? 1u : 0u) | (k < h1 ? 2u : 0u) | (k < h2 ? 4u : 0u) | (k < h3 ? 8u : 0u);
+                // which quadrants blended the entry: its four masks in the forward's log (32 bytes per list position, coalesced over the
+                // staging threads) instead of the reach test per quadrant (gsr_quad_mask: ~100 instructions, six square roots).  A slot
+                // is valid for k < the quadrant's last contributor (the forward stores whole windows, zeros where nothing blended; behind
+                // its exit nothing was stored).  The walk then visits exactly the (entry, quadrant) pairs that blend.
+                const ulonglong2* mp = reinterpret_cast<const ulonglong2*>(blend_log + gsr_blend_log_slot(r0 + k, 0u));
+                const ulonglong2 m01 = mp[0], m23 = mp[1];
+                qm = ((m01.x != 0ull && k < h0) ? 1u : 0u) | ((m01.y != 0ull && k < h1) ? 2u : 0u) |
+                     ((m23.x != 0ull && k < h2) ? 4u : 0u) | ((m23.y != 0ull && k < h3) ? 8u : 0u);
             }
             if (!keep) row = GSR_NO_ROW;
         }
