@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             // conservative skip threshold on `power` (see header); opacity <= 0 or NaN never skips; clamped to -80 (see below)
             const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
             s_a[tid] = q0;
-            s_b[tid] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress));
+            // (LOG: .w = the entry's index in the list + 1, i.e. `contributor` of forward.cu:322 itself: the blend copies it)
+            s_b[tid] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress + (LOG ? 1u : 0u)));
             s_c[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
         }
         __syncthreads();
@@ -181,7 +182,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                         unsigned long long blended = 0ull;
                         const unsigned long long m_maybe = __builtin_amdgcn_ballot_w64(maybe);
                         if (m_maybe != 0ull) {  // wave-uniform
-                            const unsigned long long m1 = m_maybe & __builtin_amdgcn_ballot_w64(px != PARKED) & __builtin_amdgcn_ballot_w64(power <= 0.0f);
+                            // (no `px != PARKED` term: a parked lane has dx = -1e30, so conic.x dx^2 -- conic.x > 0 for every listed splat -- is +inf
+                            // and power -inf or NaN: it fails `maybe`, which is what parking a pixel means; the compare was a ninth of the slow path's
+                            // non-fp32 instructions)
+                            const unsigned long long m1 = m_maybe & __builtin_amdgcn_ballot_w64(power <= 0.0f);
                             const float alpha = fminf(0.99f, b.y * gsr_expf_blend(power));
                             const unsigned long long m2 = m1 & __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
                             const float test_T = T * (1.0f - alpha);
@@ -199,7 +203,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                 "v_fmac_f32 %[C1], %[t1], %[T]\n"
                                 "v_fmac_f32 %[C2], %[t2], %[T]\n"
                                 "v_mov_b32 %[T], %[tT]\n"
-                                "v_add_u32 %[lc], 1, %[bw]\n"                      // = `contributor` of forward.cu:322
+                                "v_mov_b32 %[lc], %[bw]\n"                         // = `contributor` of forward.cu:322 (staged as index + 1)
                                 "s_mov_b64 exec, -1\n"
                                 : [px] "+v"(px), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [T] "+v"(T), [lc] "+v"(last_contributor),
                                   [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
