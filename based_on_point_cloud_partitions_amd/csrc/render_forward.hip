@@ -50,9 +50,14 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                                              float* __restrict__ out_color, unsigned long long* blend_log,
                                                              uint32_t* __restrict__ quad_hi)
 {
-    __shared__ float4 s_a[256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)];  // mx, my, conic.x, conic.y          (+4: padding entries for the unrolled walk)
-    __shared__ float4 s_b[256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)];  // conic.z, opacity, pthr, index of the entry in the tile's list (uint bits)
-    __shared__ float4 s_c[256];  // r, g, b, Gaussian id (uint bits)
+    // One 48-byte record per staged entry (round 5; three separate arrays before): a = mx, my, conic.x, conic.y; b = conic.z, opacity, pthr,
+    // index of the entry in the tile's list (uint bits); c = r, g, b, Gaussian id (uint bits).  The walk reads an entry with wave-uniform
+    // addresses: with one stride, ONE address register serves a, the two halves of b and c through the instructions' offsets -- the slow
+    // path re-made two addresses (v_mov from an SGPR: 1.75 ns each) per visit.  (+4: padding entries for the unrolled walk)
+    __shared__ float4 s_rec[3 * (256 + (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4))];
+#define s_a(j) s_rec[3 * (j)]
+#define s_b(j) s_rec[3 * (j) + 1]
+#define s_c(j) s_rec[3 * (j) + 2]
     __shared__ int s_done[4];
     __shared__ int s_wcnt[4];    // entries each wave keeps after the tile-level rejection
     __shared__ unsigned long long s_qm[QUAD ? 4 : 1][4];  // QUAD: per blend wave (quadrant), per staging wave: the staged entries that can reach it
@@ -86,8 +91,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
     bool wave_done = !gsr_any(px != PARKED);
 
     if (QUAD && tid < (GSR_FWD_GROUP > 4 ? GSR_FWD_GROUP : 4)) {  // padding entries that can never pass the range test (the walk takes entries four at a time)
-        s_a[256 + tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
-        s_b[256 + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
+        s_a(256 + tid) = make_float4(-PARKED, -PARKED, 1.f, 0.f);
+        s_b(256 + tid) = make_float4(1.f, 0.f, INFINITY, 0.f);
     }
     // LOG: the masks of the window being walked (lane j: entry j of the window) and the slot of (list position `lane` of the tile, this
     // wave's quadrant): the window starting at list position p stores at log_lane + 4 p
@@ -117,10 +122,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
         if (qm != 0u) {
             // conservative skip threshold on `power` (see header); opacity <= 0 or NaN never skips; clamped to -80 (see below)
             const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
-            s_a[tid] = q0;
+            s_a(tid) = q0;
             // (LOG: .w = the entry's index in the list + 1, i.e. `contributor` of forward.cu:322 itself: the blend copies it)
-            s_b[tid] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress + (LOG ? 1u : 0u)));
-            s_c[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
+            s_b(tid) = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress + (LOG ? 1u : 0u)));
+            s_c(tid) = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
         }
         __syncthreads();
         GSR_FPROF_MARK(2);
@@ -144,8 +149,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
 #pragma unroll
                 for (int u = 0; u < GSR_FWD_GROUP; u++) {
                     const int j = jj[u];
-                    const float4 a = s_a[j];
-                    const float4 b = s_b[j];
+                    const float4 a = s_a(j);
+                    const float4 b = s_b(j);
                     const float dx = a.x - px, dy = a.y - pixf_y;
                     // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
                     const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                     if (test_T < 0.0001f) {
                                         px = PARKED;  // done
                                     } else {
-                                        const float4 c = s_c[j];
+                                        const float4 c = s_c(j);
                                         // CONTRACT-FMA: C += (f*alpha)*T
                                         C0 = __builtin_fmaf(c.x * alpha, T, C0);
                                         C1 = __builtin_fmaf(c.y * alpha, T, C1);
@@ -191,7 +196,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                             const float test_T = T * (1.0f - alpha);
                             const unsigned long long m_done = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
                             blended = m2 & ~m_done;
-                            const float4 c = s_c[j];
+                            const float4 c = s_c(j);
                             float t0, t1, t2;
                             asm volatile(
                                 "v_cndmask_b32 %[px], %[px], %[parked], %[md]\n"   // done: parked
@@ -257,15 +262,15 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
         const int kept = __builtin_amdgcn_readfirstlane(s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
         if (keep) {  // order-preserving compaction (the walk must stay front to back)
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            s_a[pos] = q0;
+            s_a(pos) = q0;
             // walk threshold clamped to -80: below it alpha < op * e^-80, which no opacity turns into 1/255, and the blend's
             // exp then never sees an argument outside [-80, 0]
-            s_b[pos] = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress));
-            s_c[pos] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
+            s_b(pos) = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress));
+            s_c(pos) = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
         }
         if (tid < 4) {  // padding entries that can never pass the range test (walk runs in groups of 4, no bounds checks)
-            s_a[kept + tid] = make_float4(-PARKED, -PARKED, 1.f, 0.f);
-            s_b[kept + tid] = make_float4(1.f, 0.f, INFINITY, 0.f);
+            s_a(kept + tid) = make_float4(-PARKED, -PARKED, 1.f, 0.f);
+            s_b(kept + tid) = make_float4(1.f, 0.f, INFINITY, 0.f);
         }
         __syncthreads();
         if (!wave_done) {
@@ -273,8 +278,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int j = j0 + u;
-                    const float4 a = s_a[j];
-                    const float4 b = s_b[j];
+                    const float4 a = s_a(j);
+                    const float4 b = s_b(j);
                     const float dx = a.x - px, dy = a.y - pixf_y;
                     // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
                     const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
@@ -290,7 +295,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                 if (test_T < 0.0001f) {
                                     px = PARKED;  // done
                                 } else {
-                                    const float4 c = s_c[j];
+                                    const float4 c = s_c(j);
                                     // CONTRACT-FMA: C += (f*alpha)*T
                                     C0 = __builtin_fmaf(c.x * alpha, T, C0);
                                     C1 = __builtin_fmaf(c.y * alpha, T, C1);
@@ -329,6 +334,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             for (int t = 0; t < 5; t++) atomicAdd(&g_fwd_prof[t], fprof[t]);
     }
 }
+
+#undef s_a
+#undef s_b
+#undef s_c
 
 }  // namespace
 
