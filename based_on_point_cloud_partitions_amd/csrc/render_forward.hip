@@ -149,8 +149,14 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
 #pragma unroll
                 for (int u = 0; u < GSR_FWD_GROUP; u++) {
                     const int j = jj[u];
-                    const float4 a = s_a(j);
-                    const float4 b = s_b(j);
+                    // the entry's record through ONE address register for the whole visit: the byte offset is moved into a VGPR by an asm
+                    // the compiler cannot see through -- a wave-uniform address it would rather re-make from the scalar register (a second
+                    // v_mov, 1.75 ns) in the slow path than keep
+                    uint32_t rec_off;
+                    asm("v_mov_b32 %0, %1" : "=v"(rec_off) : "s"((uint32_t)j * 48u));
+                    const float4* rec_j = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + rec_off);
+                    const float4 a = rec_j[0];
+                    const float4 b = rec_j[1];
                     const float dx = a.x - px, dy = a.y - pixf_y;
                     // CONTRACT-FMA: power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy
                     const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
@@ -165,7 +171,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                     if (test_T < 0.0001f) {
                                         px = PARKED;  // done
                                     } else {
-                                        const float4 c = s_c(j);
+                                        const float4 c = rec_j[2];
                                         // CONTRACT-FMA: C += (f*alpha)*T
                                         C0 = __builtin_fmaf(c.x * alpha, T, C0);
                                         C1 = __builtin_fmaf(c.y * alpha, T, C1);
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                             const float test_T = T * (1.0f - alpha);
                             const unsigned long long m_done = m2 & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
                             blended = m2 & ~m_done;
-                            const float4 c = s_c(j);
+                            const float4 c = rec_j[2];
                             float t0, t1, t2;
                             asm volatile(
                                 "v_cndmask_b32 %[px], %[px], %[parked], %[md]\n"   // done: parked
