@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
             // conservative skip threshold on `power` (see header); opacity <= 0 or NaN never skips; clamped to -80 (see below)
             const float pthr = q1.y > 0.f ? __logf(1.0f / (255.0f * q1.y)) - 1e-3f : -INFINITY;
             s_a(tid) = q0;
-            // (LOG: .w = the entry's index in the list + 1, i.e. `contributor` of forward.cu:322 itself: the blend copies it)
-            s_b(tid) = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress + (LOG ? 1u : 0u)));
+            // (.w = the entry's index in the list + 1, i.e. `contributor` of forward.cu:322 itself: the blend copies it)
+            s_b(tid) = make_float4(q1.x, q1.y, fmaxf(pthr, -80.0f), __uint_as_float((uint32_t)progress + 1u));
             s_c(tid) = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
         }
         __syncthreads();
@@ -162,30 +162,11 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                     const float q = __builtin_fmaf(a.z * dx, dx, (b.x * dy) * dy);
                     const float power = __builtin_fmaf(-0.5f, q, -((a.w * dx) * dy));
                     const bool maybe = power >= b.z;
-                    if (!LOG) {
-                        if (gsr_any(maybe)) {  // wave-uniform
-                            if (maybe && px != PARKED && power <= 0.0f) {
-                                const float alpha = fminf(0.99f, b.y * gsr_expf_blend(power));
-                                if (alpha >= 1.0f / 255.0f) {
-                                    const float test_T = T * (1.0f - alpha);
-                                    if (test_T < 0.0001f) {
-                                        px = PARKED;  // done
-                                    } else {
-                                        const float4 c = rec_j[2];
-                                        // CONTRACT-FMA: C += (f*alpha)*T
-                                        C0 = __builtin_fmaf(c.x * alpha, T, C0);
-                                        C1 = __builtin_fmaf(c.y * alpha, T, C1);
-                                        C2 = __builtin_fmaf(c.z * alpha, T, C2);
-                                        T = test_T;
-                                        last_contributor = __float_as_uint(b.w) + 1u;  // = `contributor` of forward.cu:322
-                                    }
-                                }
-                            }
-                        }
-                    } else {
-                        // LOG: the same decisions (forward.cu:332-352) as 64-bit LANE MASKS in scalar registers -- each compare is its own
-                        // ballot, the conjunctions are scalar ANDs -- so the mask of the lanes that blend is there for the log without a
-                        // VALU slot, and the blend itself runs under EXEC = that mask (one asm block: the compiler cannot express "these
+                    {
+                        // The decisions of forward.cu:332-352 as 64-bit LANE MASKS in scalar registers (round 5; nested per-lane branches
+                        // before: three exec save / restore pairs and a second address per visit) -- each compare is its own
+                        // ballot, the conjunctions are scalar ANDs -- so the mask of the lanes that blend is there (for the log, LOG) without
+                        // a VALU slot, and the blend itself runs under EXEC = that mask (one asm block: the compiler cannot express "these
                         // lanes" from a scalar mask without rebuilding it per lane).  alpha / test_T are evaluated by all lanes; a lane
                         // outside the masks keeps nothing of them.  Same arithmetic per blending lane as the nested form: bit-identical.
                         // (The block leaves EXEC = all ones: every lane of the 256-thread workgroup is active here -- the walk is under
@@ -222,7 +203,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int g
                                   [al] "v"(alpha), [tT] "v"(test_T), [bw] "v"(b.w));
                             // the entry's mask into lane (entry's index in the window) of the window's pair.  (A padding entry of the
                             // unrolled walk never gets here: its threshold is +inf.)
-                            if (GSR_FWD_LOG_ABLATE != 2)
+                            if (LOG && GSR_FWD_LOG_ABLATE != 2)
                                 // (M0 is on the clobber list although the compiler warns that it "may not preserve" reserved registers: on gfx9 it
                                 // loads M0 right in front of each instruction that reads it and keeps nothing there across other code)
                                 asm volatile("s_mov_b32 m0, %4\n s_nop 0\n v_writelane_b32 %0, %2, m0\n v_writelane_b32 %1, %3, m0"  // (one SGPR + m0 per VALU)
