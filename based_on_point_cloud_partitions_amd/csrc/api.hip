@@ -225,20 +225,22 @@ static bool gsr_variant_store(const char* name, int value)
 // those instances lie outside the alpha >= 1/255 ellipse (gsr_reach_mask) and cannot contribute to any pixel.  Leaving them out
 // changes no pixel and no gradient; GSR_CULL=0 keeps the reference's lists bit for bit (sort keys, point_list, ranges, n_contrib).
 bool gsr_cull_enabled() { return gsr_variant("CULL", 1) && gsr_variant("BIN", 1); }
-// The blend log (render_forward.hip) is written by the quadrant walk of the forward only.  GSR_BLEND_LOG: 0 never, 2 always, 1 (default) when
-// the mean length of the reference's tile lists is below GSR_BLEND_LOG_LIST (700): measured (round 5, profiles/README.md) the log takes
-// 3-17 % off the step where lists are short (500k Gaussians at 1080p, mean 467: 0.695 -> 0.681 ms; 10k at 256x256: 0.160 -> 0.149;
-// 150k at 640x360: 0.419 -> 0.391) and costs 1-1.5 % where they are long (1M, mean 930: 0.960 -> 0.971; 2M, 1866: 1.629 -> 1.649 -- the
-// forward pays 6 % for writing it and the four-waves-per-tile backward of those scenes gains nothing from reading it).  Forward and backward
-// of one frame get the same answer because both ask with the frame's own R and image size; the switches are read at launch time, so
-// change them between frames, not between a forward and its backward.
+// The blend log (render_forward.hip) is written by the quadrant walk of the forward only.  GSR_BLEND_LOG: 0 never, 1 (default) / 2 always;
+// GSR_BLEND_LOG_LIST = n > 0 restricts it to frames whose mean reference tile list is shorter than n (0, the default: no restriction).
+// Measured with the final kernels of round 5 (profiles/README.md): the log pays at every density -- 500k Gaussians at 1080p (mean list 467)
+// 0.689 -> 0.649 ms per step, 10k at 256x256 0.160 -> 0.139, 1 M (934) kernels 0.545 -> 0.538, 1.5 M (1,400) 0.647 -> 0.636, 2 M (1,866)
+// 0.812 -> 0.793 (the forward pays ~0.012-0.02 ms for writing it, the backward gains 0.02-0.04).  (An earlier build of the round wrote it
+// only below a mean list of 700: its four-waves-per-tile backward gained nothing then.)  Forward and backward of one frame get the same
+// answer because both ask with the frame's own R and image size; the switches are read at launch time, so change them between frames,
+// not between a forward and its backward.
 bool gsr_blend_log_for(int64_t R, int W, int H)
 {
     const int mode = gsr_variant("BLEND_LOG", 1);
     if (mode == 0 || R <= 0 || gsr_variant("QUAD", 1) != 1 || gsr_variant("WAVE8X8", 1) == 0) return false;
-    if (mode == 2) return true;
+    const int limit = gsr_variant("BLEND_LOG_LIST", 0);
+    if (limit <= 0) return true;
     const int gx = (W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (H + GSR_TILE_Y - 1) / GSR_TILE_Y;
-    return (float)R / (float)(gx * gy) < (float)gsr_variant("BLEND_LOG_LIST", 700);
+    return (float)R / (float)(gx * gy) < (float)limit;
 }
 
 extern "C" {

@@ -29,7 +29,7 @@
 // alpha / G are recomputed so that the set of blended pairs is exactly the forward's (see FAST_EXP below).
 //
 // TWO kernels live in this file.  render_backward_kernel (rounds 1-4) re-derives every blend decision from the geometry, as the reference
-// does.  render_backward_log_kernel (round 5) reads them from the BLEND LOG the forward leaves when tile lists are short (api.hip,
+// does.  render_backward_log_kernel (round 5, the default) reads them from the BLEND LOG the forward leaves (api.hip,
 // gsr_blend_log_for; render_forward.hip): one 64-bit lane mask per (list entry, quadrant) visit -- see its own header below.  Staging, the
 // wave reduction, the LDS sums, the gradient rows and the work split are the same in both.
 #include "common.h"

@@ -39,7 +39,7 @@ const char* gsr_last_error(void);
  * rasterizer_impl.h:67-73) and of the backward scratch (one 36-byte gradient row -- nine floats -- per instance).
  * Binning: 24 bytes per instance as the reference (keys + values, double-buffered) + 4.25 for the radix path + 32 for the blend log
  * (four 64-bit lane masks per list position: which pixels of each 8x8 quadrant blended the entry, written by the forward for the
- * backward when tile lists are short).  Image: 8 bytes per pixel + 8 per tile as the reference + 16 per tile (last contributor of
+ * backward).  Image: 8 bytes per pixel + 8 per tile as the reference + 16 per tile (last contributor of
  * each quadrant). */
 size_t gsr_geometry_bytes(int P);
 size_t gsr_image_bytes(int W, int H);

@@ -21,13 +21,14 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["culled", "reference"])
 def tile_list_mode(request):
     """Every test of this file runs twice: with the default tile lists (instances the splat cannot reach are left out, GSR_CULL=1)
-    and with the reference's lists (GSR_CULL=0: sort keys, point_list, ranges and n_contrib bit for bit).  The second run also forces
-    the blend log (GSR_BLEND_LOG=2; by default the library writes it only where tile lists are short, api.hip gsr_blend_log_for): every
-    scene goes through the backward that re-derives the blend decisions AND through the one that reads the forward's."""
+    and with the reference's lists (GSR_CULL=0: sort keys, point_list, ranges and n_contrib bit for bit).  The second run also switches
+    the blend log off (GSR_BLEND_LOG=0; by default the forward logs its blend decisions for the backward, api.hip gsr_blend_log_for):
+    every scene goes through the backward that reads the forward's decisions AND through the one that re-derives them, as the reference
+    does.  (Log + reference lists: tests/test_partitions_gpu.py at full size, tests/test_variants.py.)"""
     from based_on_point_cloud_partitions_amd import _lib
 
     _lib.set_variant("CULL", 1 if request.param == "culled" else 0)
-    _lib.set_variant("BLEND_LOG", 1 if request.param == "culled" else 2)
+    _lib.set_variant("BLEND_LOG", 1 if request.param == "culled" else 0)
     yield request.param
     _lib.set_variant("CULL", 1)
     _lib.set_variant("BLEND_LOG", 1)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = dict(QUAD=1, CULL=1, BIN=2, LPT=1, MAILBOX=1, BWD_FASTEXP=1, BWD_NQ=0, KEYS=0, WAVE8X8=1, EARLY=1, BANDS=8,
                 GB_BLOCK=128, PRE_DIRECT=1, GB_DIRECT=1, GB_RK=1, BWD_PADLDS=0, FWD_PADLDS=0, GB_BALANCED=1, MID_HINT=1, EMIT_SCAN=1,
-                BLEND_LOG=1, BLEND_LOG_LIST=700)
+                BLEND_LOG=1, BLEND_LOG_LIST=0)
 ALTERNATIVES = [
     dict(QUAD=0),                 # forward: every wave walks the whole tile list
     dict(QUAD=0, CULL=0),         # ... over the reference's lists
@@ -42,8 +42,8 @@ ALTERNATIVES = [
     dict(MID_HINT=2),             # ... never: lists of more than 2048 entries are left to tile_sort_small_kernel's in-place network
     dict(BLEND_LOG=0),            # no blend log: the backward re-derives every blend decision (render_backward_kernel, rounds 1-4)
     dict(BLEND_LOG=0, BWD_NQ=1), dict(BLEND_LOG=0, BWD_NQ=2, CULL=0), dict(BLEND_LOG=0, BWD_FASTEXP=0),
-    dict(BLEND_LOG=2, BWD_NQ=1), dict(BLEND_LOG=2, BWD_NQ=2), dict(BLEND_LOG=2, CULL=0),  # ... always (default: by the mean list length)
-    dict(BLEND_LOG_LIST=1),       # the automatic choice says "lists too long": no log
+    dict(BLEND_LOG=1, BWD_NQ=1), dict(BLEND_LOG=1, BWD_NQ=2), dict(BLEND_LOG=1, CULL=0),  # the log with every work split / the reference's lists
+    dict(BLEND_LOG_LIST=1),       # the optional list-length limit says "lists too long": no log
     dict(BWD_NQ=2, BWD_PADLDS=6144),  # the occupancy experiments' switches: fewer workgroups per CU, same results
     dict(FWD_PADLDS=20000, BWD_PADLDS=9728),
 ]
