@@ -866,6 +866,9 @@ def main():
             "ms_per_step_incl_closing_barrier": round(1e3 * elapsed_incl_barrier / args.steps, 4),
             "closing_barrier_ms": round(1e3 * (elapsed_incl_barrier - elapsed), 3), "opening_barrier_ms": round(opening_barrier_ms, 3),
             "ms_per_step_reference_lists": round(ref_lists_ms, 4) if ref_lists_ms is not None else None,
+            # round 5: the forward logs which pixels blended each (list entry, quadrant) visit and the backward reads that instead of
+            # re-deriving it (GSR_BLEND_LOG=0 switches it off, GSR_BLEND_LOG_LIST=n limits it to mean lists below n)
+            "blend_log": {"GSR_BLEND_LOG": _lib.get_variant("BLEND_LOG", 1), "GSR_BLEND_LOG_LIST": _lib.get_variant("BLEND_LOG_LIST", 0)},
             "knn_init_ms": knn_ms,
             "knn_points_per_s": round(P / (knn_ms * 1e-3), 1),
             # the kNN is not bandwidth-bound (its ~120 B per point are read once; the candidate points come out of LDS): its work is the
