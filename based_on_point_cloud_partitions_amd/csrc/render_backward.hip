@@ -478,9 +478,12 @@ __device__ unsigned long long g_blend_prof[8];  // ([4] holds the zero rows + en
 // Why it pays (tools/smem_probe.hip, profiles/README.md round 5): a SALU instruction costs 1.74 ns per SIMD on gfx950 -- more than a
 // plain VALU instruction (1.1 ns) -- and the decision chains were ~27 scalar instructions per visit (ballot, s_and, s_cmp, s_cbranch, four
 // times over) beside ~10 of the visit's 44 VALU issue slots; both pipes of the old kernel ran at 75-90 %.
-// The walk still needs the splat's reach bit per quadrant (a slot the forward did not visit holds garbage) and the quadrant's last
-// contributor (slots behind the forward wave's exit were never written): both are applied by the staging threads (gsr_quad_mask,
-// k < max n_contrib of the quadrant), so a staged bit means "the forward wrote this slot".
+// Which quadrants an entry is walked for also comes from the log: the forward stores whole 64-entry windows (zeros where nothing
+// blended), so a staging thread reads its entry's four masks and keeps a quadrant bit where the mask is non-zero and the slot is one the
+// forward wrote (k < the quadrant's last contributor, quad_hi: behind the forward wave's exit nothing was stored) -- no reach test per
+// quadrant (gsr_quad_mask: ~100 instructions, six square roots), and the walk visits exactly the (entry, quadrant) pairs that blend.
+// The kernel is VALU-throughput-bound (an instruction added per entry costs exactly its issue time, profiles/README.md): 25 instructions
+// per visit, 38 per wave reduction, ~9 per entry.
 template <int NQ>
 __global__ void __launch_bounds__(64 * (4 / NQ)) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE ? GSR_BWD_WPE : 8)))
 render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ranges,
@@ -496,7 +499,7 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
     __shared__ float4 s_a[BATCH];    // mx, my, conic.x, conic.y
     __shared__ float4 s_b[BATCH];    // conic.z, opacity, -, r
     __shared__ float2 s_c[BATCH];    // g, b
-    __shared__ uint32_t s_row[BATCH];  // gradient row index | (quadrants whose log slot the forward wrote) << 28
+    __shared__ uint32_t s_row[BATCH];  // gradient row index | (quadrants that blended the entry, by the log) << 28
     constexpr int NACC = NQ == 2 ? 1 : 2;
     __shared__ float s_acc[NACC * BATCH * NV];
 
@@ -577,8 +580,7 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
     // (the next round's Gaussian ids loaded a round ahead -- one of the two dependent load latencies of a staging round behind the
     // previous walk -- measured, round 5: 0.2913 vs 0.2917 ms, not kept)
     for (int i = 0; i < rounds; i++) {
-        // ---- stage this batch (back to front): as render_backward_kernel, plus: a quadrant bit is kept only for k < the quadrant's last
-        // contributor ----
+        // ---- stage this batch (back to front): as render_backward_kernel, but the quadrant bits come from the log ----
         const uint32_t progress = (uint32_t)i * BATCH + tid;
         uint32_t qm = 0, row = GSR_NO_ROW;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
@@ -661,7 +663,8 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
             Masks opM0 = load_masks(j), opM1;
             auto entry = [&](const float4& a, const float4& b, const float2& c, const Masks& mk, float4& na, float4& nb, float2& nc,
                              Masks& nm) __attribute__((always_inline)) -> bool {
-                // this entry's masks: the forward's if it wrote one (staged bit), else nothing
+                // this entry's masks: the forward's where the quadrant's bit was staged (valid slot, non-zero mask), else nothing (the slot may
+                // never have been written)
                 unsigned long long mq[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; q++) mq[q] = ((bq[q] >> jj) & 1ull) ? mk.m[q] : 0ull;

@@ -1,4 +1,5 @@
-// Front-to-back alpha compositing, one 16x16 tile per 256-thread workgroup (4 wave64s, each a 16x4 pixel strip).
+// Front-to-back alpha compositing, one 16x16 tile per 256-thread workgroup (4 wave64s, each an 8x8 quadrant of the tile; 16x4 strips with
+// GSR_WAVE8X8=0).
 // Replaces renderCUDA, cuda_rasterizer/forward.cu:261-374.
 //
 // Per batch of 256 list entries the workgroup gathers each splat's packed 48-byte record into LDS
@@ -33,14 +34,15 @@ __device__ unsigned long long g_fwd_prof[8];
 // LOG (QUAD only): the blend log.  Every (list entry, 8x8 quadrant) visit of the walk that blends leaves the 64-bit mask of the lanes
 // (pixels) that blended the entry -- the outcome of every decision of forward.cu:332-352 for 64 pixels -- at
 // blend_log[gsr_blend_log_slot(list position, quadrant)].  The backward (render_backward.hip, log walk) reads the masks instead of re-deriving
-// them: no range test, no threshold test, no alpha test, no n_contrib bookkeeping, and the decisions are the forward's by construction.
+// them: no range test, no threshold test, no alpha test, no n_contrib bookkeeping, no reach test per quadrant, and the decisions are the
+// forward's by construction.
 // How the masks get to memory (round 5, designs measured: profiles/README.md): a mask is a ballot, i.e. it lives in scalar registers.
 // Scalar stores (s_store_dwordx2) work on gfx950 and cost no VALU slot, but one per visit made the forward 18 % slower (the scalar cache
 // takes ~4 bytes per clock per CU, every store counts on lgkmcnt like the LDS operand reads, and its data registers must stay untouched
 // until it completes).  So a wave keeps the masks of the 64-entry window it is walking in a VGPR pair -- lane j holds the mask of the
 // window's entry j, written with v_writelane_b32 when a visit blends -- and stores the pair once per window, one coalesced 8-byte store
 // per lane; entries it did not visit, or that blended nowhere, read as zero.  Windows the wave never walks (behind its exit) are never
-// stored: the backward knows the exit from n_contrib.
+// stored: the backward knows the exit from the quadrant's largest n_contrib, which the wave leaves in quad_hi[4 tile + quadrant].
 template <bool QUAD, bool LOG>
 __global__ void __launch_bounds__(256) render_forward_kernel(int W, int H, int gx, int gy, int wave8x8, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ ranges,
