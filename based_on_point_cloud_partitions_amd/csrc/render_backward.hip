@@ -460,6 +460,8 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
 }
 
 
+// Profiling builds of the log walk (never shipped): -DGSR_LOG_PROFILE=2 counts entries / visits / blended pixels into the same counters
+// (tools/r5_counts.py), =3 time-stamps every wave (tools/r5_wave_times.py), and
 // Phase profile of the log walk (make EXTRA=-DGSR_LOG_PROFILE=1, never in the shipped build): wave-cycles (s_memtime) per phase, summed over all
 // waves of all launches since the last gsr_debug_blend_profile call: [0] whole wave, [1] prologue, [2] staging loads + tests, [3] wait at the
 // "previous batch flushed" barrier, [4] LDS writes + barrier, [5] walk, [6] wait at the end-of-walk barrier (the other wave is still walking),
@@ -467,8 +469,11 @@ render_backward_kernel(int W, int H, int gx, int gy, const uint32_t* __restrict_
 #ifndef GSR_LOG_PROFILE
 #define GSR_LOG_PROFILE 0
 #endif
+#if GSR_LOG_PROFILE == 3
+__device__ unsigned long long g_wave_times[4 * 32768];  // per wave of the last launch: start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID
+#endif
 __device__ unsigned long long g_blend_prof[8];  // ([4] holds the zero rows + end of the wave in profiling builds: the LDS writes are folded into [3])
-#define GSR_PROF_MARK(slot) do { if (GSR_LOG_PROFILE) { const long long t_ = clock64(); prof[slot] += (unsigned long long)(t_ - t_last); t_last = t_; } } while (0)
+#define GSR_PROF_MARK(slot) do { if (GSR_LOG_PROFILE == 1) { const long long t_ = clock64(); prof[slot] += (unsigned long long)(t_ - t_last); t_last = t_; } } while (0)
 
 // ---- the log walk (round 5) ----------------------------------------------------------------------------------------------------------
 // The same kernel fed with the forward's blend log (render_forward.hip): for every (list entry, quadrant) visit the forward made, the
@@ -516,6 +521,9 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
     const uint32_t h0 = __builtin_amdgcn_readfirstlane(quad_hi[4 * tile]), h1 = __builtin_amdgcn_readfirstlane(quad_hi[4 * tile + 1]);
     const uint32_t h2 = __builtin_amdgcn_readfirstlane(quad_hi[4 * tile + 2]), h3 = __builtin_amdgcn_readfirstlane(quad_hi[4 * tile + 3]);
     const uint32_t hi = max(max(h0, h1), max(h2, h3));  // number of list entries that matter to any pixel of the tile
+#if GSR_LOG_PROFILE == 3
+    const unsigned long long wt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = GSR_LOG_PROFILE ? clock64() : 0;
     const long long t_begin = t_last;
@@ -620,6 +628,11 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
             if (!keep) row = GSR_NO_ROW;
         }
         GSR_PROF_MARK(2);
+        if (GSR_LOG_PROFILE == 2) {  // counting build: [6] staged entries some quadrant blended, [7] their quadrant bits
+            prof[6] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(qm != 0u));
+            prof[7] += (unsigned long long)(__popcll(__builtin_amdgcn_ballot_w64((qm & 1u) != 0u)) + __popcll(__builtin_amdgcn_ballot_w64((qm & 2u) != 0u)) +
+                                            __popcll(__builtin_amdgcn_ballot_w64((qm & 4u) != 0u)) + __popcll(__builtin_amdgcn_ballot_w64((qm & 8u) != 0u)));
+        }
         __syncthreads();  // previous batch flushed
         GSR_PROF_MARK(3);
         if (tid < BATCH) {
@@ -735,6 +748,7 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                 // are independent and interleave) and ends in its own copy of the reduction: nothing is merged behind the branches.
                 float W0, WX0, DX0, AT0, W1, WX1, DX1, AT1;
                 if constexpr (NQ == 1) {
+                    if (GSR_LOG_PROFILE == 2) { prof[1]++; prof[mq[0] != 0ull ? 3 : 4]++; prof[5] += (unsigned long long)__popcll(mq[0]); }
                     if (mq[0] != 0ull) {
                         visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
                         request_next();
@@ -743,6 +757,10 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                         request_next();
                 } else {
                     const bool v0 = mq[0] != 0ull, v1 = mq[NQ - 1] != 0ull;
+                    if (GSR_LOG_PROFILE == 2) {  // counting build: [1] entries walked, [2] both quadrants, [3] one, [4] none, [5] blended pixels
+                        prof[1]++; prof[v0 && v1 ? 2 : (v0 || v1) ? 3 : 4]++;
+                        prof[5] += (unsigned long long)(__popcll(mq[0]) + __popcll(mq[NQ - 1]));
+                    }
                     if (v0 && v1) {
                         visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
                         visit(std::integral_constant<int, NQ - 1>{}, mq[NQ - 1], W1, WX1, DX1, AT1);
@@ -787,7 +805,16 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
         GSR_PROF_MARK(7);
     }
     zero_rows();
-    if (GSR_LOG_PROFILE) {
+#if GSR_LOG_PROFILE == 3
+    if (lane == 0) {  // time-stamp build: this wave's start, end, list length | HW_ID, entries walked | XCC_ID
+        const size_t wi = ((size_t)blockIdx.x * WPT + (size_t)wave) & 32767u;
+        g_wave_times[4 * wi] = wt_begin;
+        g_wave_times[4 * wi + 1] = __builtin_amdgcn_s_memrealtime();
+        g_wave_times[4 * wi + 2] = ((unsigned long long)total << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_wave_times[4 * wi + 3] = ((unsigned long long)hi << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
+    if (GSR_LOG_PROFILE == 1 || GSR_LOG_PROFILE == 2) {
         GSR_PROF_MARK(4);
         prof[0] = (unsigned long long)(clock64() - t_begin);
         if (lane == 0)
@@ -831,6 +858,20 @@ void gsr_launch_render_backward(int W, int H, const uint32_t* ranges, const uint
 }
 
 int gsr_render_backward_ablate() { return GSR_ABLATE; }
+
+#if GSR_LOG_PROFILE == 3
+// time-stamp builds only (tools/r5_wave_times.py; not in the header, not in the shipped library): copies and clears the per-wave time stamps
+// of the last log-walk launch
+extern "C" __attribute__((visibility("default"))) int gsr_debug_wave_times(unsigned long long* out, int words)
+{
+    if (words > 4 * 32768) words = 4 * 32768;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), (size_t)words * 8) != hipSuccess) return -1;
+    static unsigned long long zeros[4 * 32768];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_times), zeros, sizeof(zeros)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 // copies and clears the phase profile of the log walk (all zero unless built with -DGSR_LOG_PROFILE=1)
 int gsr_blend_profile_fetch(unsigned long long* out8)

@@ -162,6 +162,8 @@ CONFIGS = {
     # ... and two smaller images of the same scene (2,500 / 920 tiles), used to place the tile-count threshold of that choice
     "mid800": dict(P=300_000, W=800, H=800, focal=600.0, cameras=8),
     "mid640": dict(P=150_000, W=640, H=360, focal=400.0, cameras=8),
+    # ... and cfg2's scene at four times the pixels (32,400 tiles, the same list lengths): many more tiles than wave slots
+    "uhd500k": dict(P=500_000, W=3840, H=2160, focal=2400.0, cameras=8),
 }
 
 

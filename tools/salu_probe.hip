@@ -15,6 +15,7 @@ template <int KIND>
 __global__ void __launch_bounds__(256) k(float* out, int iters)
 {
     float a = threadIdx.x * 1e-3f, b = 1.0001f, c = 0.5f, d = 0.25f;
+    float2 p0 = {a, 1.f}, p1 = {1.0001f, 0.999f}, p2 = {0.5f, 0.25f}, p3 = {0.125f, 0.3f};
     uint32_t va = threadIdx.x, vb = threadIdx.x * 3u;
     unsigned long long s0 = 0x1234567ull + blockIdx.x, s1 = 0xFFFF0000FFFFull, s2 = 0xF0F0F0F0ull, s3 = 0xFF00FF00FFull;
     uint32_t t0 = blockIdx.x + 1, t1 = 77, t2 = 5, t3 = 9;
@@ -41,7 +42,16 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
         else if (KIND == 19) asm volatile(R16("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %0\n v_fma_f32 %3, %3, %0, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         else if (KIND == 20) asm volatile(R16("v_cndmask_b32 %0, 0, %1, %4\n v_cndmask_b32 %1, 0, %2, %4\n v_cndmask_b32 %2, 0, %3, %4\n v_cndmask_b32 %3, 0, %0, %4\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(s1));
         else if (KIND == 21) asm volatile(R16("v_bfe_u32 %0, %1, %2, 1\n v_bfe_u32 %1, %0, %3, 1\n v_and_b32 %0, %2, %1\n v_and_b32 %1, %3, %0\n") : "+v"(va), "+v"(vb) : "s"(t0), "s"(t1));
+        else if (KIND == 22) asm volatile(R16("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %1, %1, %2, %3\n v_pk_fma_f32 %2, %2, %3, %0\n v_pk_fma_f32 %3, %3, %0, %1\n") : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+        else if (KIND == 23) asm volatile(R16("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %0\n") : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+        else if (KIND == 24) asm volatile(R16("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %1, %1, %2\n v_pk_add_f32 %2, %2, %3\n v_pk_add_f32 %3, %3, %0\n") : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+        else if (KIND == 25) asm volatile(R16("v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa\n v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 26) asm volatile(R16("v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_shl:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 27) asm volatile(R16("v_add_f32 %0, %0, %1\n v_mul_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_mul_f32 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 28) asm volatile(R16("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 29) asm volatile(R16("v_pk_mov_b32 %0, %1, %2\n v_pk_mov_b32 %1, %2, %3\n v_pk_mov_b32 %2, %3, %0\n v_pk_mov_b32 %3, %0, %1\n") : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
     }
+    if (p0.x + p1.y + p2.x + p3.y == 777.5f) out[1] = p0.x;
     if (a + b + c + d == 12345.678f || (s0 ^ s1 ^ s2 ^ s3) == 0x123456789ull || t0 + t1 + t2 + t3 == 0x7777777u || va + vb == 0x3333333u) out[0] = a;
 }
 
@@ -93,5 +103,13 @@ int main()
     run<15>("v_cmp_ne_u32 -> sgpr pair", 64, sink);
     run<20>("v_cndmask_b32 0, v, sgpr mask", 64, sink);
     run<21>("v_bfe_u32 sgpr pos / v_and_b32 sgpr", 64, sink);
+    run<22>("v_pk_fma_f32", 64, sink);
+    run<23>("v_pk_mul_f32", 64, sink);
+    run<24>("v_pk_add_f32", 64, sink);
+    run<25>("v_add_f32_dpp (bank-masked, row shifts)", 64, sink);
+    run<26>("v_mov_b32_dpp", 64, sink);
+    run<27>("v_add_f32 / v_mul_f32", 64, sink);
+    run<28>("v_mov_b32 vgpr", 64, sink);
+    run<29>("v_pk_mov_b32", 64, sink);
     return 0;
 }
