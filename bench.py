@@ -610,6 +610,20 @@ def main():
             for i in range(32):
                 step(i)
             untimed_steps += 32
+    # The timed region's own code paths once, untimed: it is the first place where the dominant stage alone carries HIP events, and in
+    # the first process on a fresh box code that runs for the first time is paged in from the image (two of two collection runs that
+    # started with this script read 0.70 ms/step behind spin-up batches at 0.648; later processes on the same box never did)
+    if use_timers:
+        _lib.profile_enable(True, stages=[dominant])
+        for i in range(32):
+            step(i)
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        _lib.profile_collect()
+        for i in range(64):  # and back to steady state
+            step(i)
+        torch.cuda.synchronize()
+        untimed_steps += 96
     _lib.profile_enable(use_timers, stages=[dominant])
     gc.disable()
     # Timed region: K steps between (barrier + device sync) and (device sync + barrier).  Each rank reads its clock right after its own
@@ -623,8 +637,11 @@ def main():
     t0 = time.perf_counter()
     t0_wall = time.time()  # one node: the ranks share this clock, so the spread of these stamps is the skew the opening barrier left
     opening_barrier_ms = 1e3 * (t0 - tb)
+    host_marks = []  # host-side progress (no sync): where the enqueueing thread stood every 32 steps -- a stall shows as a jump
     for i in range(args.steps):
         step(args.warmup + i)
+        if (i & 31) == 31:
+            host_marks.append(time.perf_counter())
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -863,6 +880,8 @@ def main():
             # that idled, see --spinup-ms) and, at N > 1, the 32 steps behind the aligning barrier
             "untimed_steps": untimed_steps, "spinup": spinup,
             "ms_per_step_cold": round(cold_ms, 4),  # the same K steps timed right after the W warm-up steps, no spin-up
+            # host-side progress inside the timed region: ms the enqueueing thread needed for each 32 steps (no device sync)
+            "timed_host_ms_per_32_steps": [round(1e3 * (b - a), 2) for a, b in zip([t0] + host_marks[:-1], host_marks)],
             "ms_per_step_incl_closing_barrier": round(1e3 * elapsed_incl_barrier / args.steps, 4),
             "closing_barrier_ms": round(1e3 * (elapsed_incl_barrier - elapsed), 3), "opening_barrier_ms": round(opening_barrier_ms, 3),
             "ms_per_step_reference_lists": round(ref_lists_ms, 4) if ref_lists_ms is not None else None,
