@@ -90,10 +90,25 @@ __device__ __forceinline__ float wave_sum9_rows(float v0, float v1, float v2, fl
         : "s"(m0), "s"(m2));
     return v0;
 }
+// XROW: the two cross-row levels through the LDS crossbar (ds_bpermute_b32 of lane ^ 16, lane ^ 32: no VALU slot but the add, the same sum
+// tree, bit-identical) instead of v_permlane16_swap / v_permlane32_swap (3.6 ns of VALU issue each + add + copy).  Measured with the log
+// walk (round 5, two alternations / one): two waves per tile (cfg2) 0.2829 / 0.2836 -> 0.2759 / 0.2761 ms; four waves per tile (2 M
+// Gaussians) 0.5858 -> 0.6063 (twice the waves on the LDS pipe) -- so the log walk uses it with two quadrants per wave only
+// (GSR_BWD_XROW: 0 never, 1 that rule, 2 always).  Round 3 had measured it slower in the kernel of the time (header above).
+#ifndef GSR_BWD_XROW
+#define GSR_BWD_XROW 1
+#endif
+template <bool XROW = false>
 __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
                                                    float v8, unsigned long long m0, unsigned long long m2)
 {
     v0 = wave_sum9_rows(v0, v1, v2, v3, v4, v5, v6, v7, v8, m0, m2);
+    if (XROW) {
+        const int lane4 = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) << 2);
+        v0 += __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 ^ 64, __float_as_int(v0)));
+        v0 += __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 ^ 128, __float_as_int(v0)));
+        return v0;
+    }
     // levels 5, 6: lane-wise across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap
     {
         const uint32_t u = __float_as_uint(v0);
@@ -740,7 +755,8 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                         if (w4) { atomicAdd(o, d[0]); atomicAdd(o + 1, d[1]); }  // LDS
                         if (w1) atomicAdd(o + 8, d[2]);
                     } else {
-                        const float tot = wave_sum9_scatter(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1, c2, M0, M2);
+                        const float tot = wave_sum9_scatter<(GSR_BWD_XROW == 2 || (GSR_BWD_XROW == 1 && NQ == 2))>(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1,
+                                                                                                                c2, M0, M2);
                         if (writer) atomicAdd(&my_acc[jcur * NV + my_slot], tot);  // LDS
                     }
                 };
