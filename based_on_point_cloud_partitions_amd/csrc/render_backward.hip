@@ -90,7 +90,7 @@ __device__ __forceinline__ float wave_sum9_rows(float v0, float v1, float v2, fl
         : "s"(m0), "s"(m2));
     return v0;
 }
-// XROW: the two cross-row levels through the LDS crossbar (ds_bpermute_b32 of lane ^ 16, lane ^ 32: no VALU slot but the add, the same sum
+// XROW: the two cross-row levels through the LDS crossbar (ds_bpermute_b32 of lane + 16, lane + 32: no VALU slot but the add, the same sum
 // tree, bit-identical) instead of v_permlane16_swap / v_permlane32_swap (3.6 ns of VALU issue each + add + copy).  Measured with the log
 // walk (round 5, two alternations / one): two waves per tile (cfg2) 0.2829 / 0.2836 -> 0.2759 / 0.2761 ms; four waves per tile (2 M
 // Gaussians) 0.5858 -> 0.6063 (twice the waves on the LDS pipe) -- so the log walk uses it with two quadrants per wave only
@@ -105,8 +105,10 @@ __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2,
     v0 = wave_sum9_rows(v0, v1, v2, v3, v4, v5, v6, v7, v8, m0, m2);
     if (XROW) {
         const int lane4 = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) << 2);
-        v0 += __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 ^ 64, __float_as_int(v0)));
-        v0 += __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 ^ 128, __float_as_int(v0)));
+        // (lane + 16, lane + 32 mod 64 rather than lane ^ 16, lane ^ 32: the constant goes into the instruction's offset field, one address
+        // register for both; the lanes of row 0 -- the only ones whose totals are used -- form the same tree (r0 + r1) + (r2 + r3))
+        v0 += __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 64, __float_as_int(v0)));
+        v0 += __int_as_float(__builtin_amdgcn_ds_bpermute(lane4 + 128, __float_as_int(v0)));
         return v0;
     }
     // levels 5, 6: lane-wise across the four rows with gfx950's v_permlane16_swap / v_permlane32_swap
