@@ -613,17 +613,24 @@ def main():
     # The timed region's own code paths once, untimed: it is the first place where the dominant stage alone carries HIP events, and in
     # the first process on a fresh box code that runs for the first time is paged in from the image (two of two collection runs that
     # started with this script read 0.70 ms/step behind spin-up batches at 0.648; later processes on the same box never did)
+    warm_marks = []
     if use_timers:
+        # (as many steps as the timed region: its 2 K events are alive at once, and the runtime's event / signal pools grow in chunks --
+        # with 32 steps here the first process on a box still showed two host-side gaps of 1 and 6 ms inside the timed region)
         _lib.profile_enable(True, stages=[dominant])
-        for i in range(32):
+        tw = time.perf_counter()
+        for i in range(args.steps):
             step(i)
+            if (i & 31) == 31:
+                warm_marks.append(time.perf_counter())
         torch.cuda.synchronize()
+        warm_marks = [round(1e3 * (b - a), 2) for a, b in zip([tw] + warm_marks[:-1], warm_marks)]
         _lib.profile_enable(False)
         _lib.profile_collect()
         for i in range(64):  # and back to steady state
             step(i)
         torch.cuda.synchronize()
-        untimed_steps += 96
+        untimed_steps += args.steps + 64
     _lib.profile_enable(use_timers, stages=[dominant])
     gc.disable()
     # Timed region: K steps between (barrier + device sync) and (device sync + barrier).  Each rank reads its clock right after its own
@@ -882,6 +889,7 @@ def main():
             "ms_per_step_cold": round(cold_ms, 4),  # the same K steps timed right after the W warm-up steps, no spin-up
             # host-side progress inside the timed region: ms the enqueueing thread needed for each 32 steps (no device sync)
             "timed_host_ms_per_32_steps": [round(1e3 * (b - a), 2) for a, b in zip([t0] + host_marks[:-1], host_marks)],
+            "warm_pass_host_ms_per_32_steps": warm_marks,  # the same path run once, untimed, right before (see above)
             "ms_per_step_incl_closing_barrier": round(1e3 * elapsed_incl_barrier / args.steps, 4),
             "closing_barrier_ms": round(1e3 * (elapsed_incl_barrier - elapsed), 3), "opening_barrier_ms": round(opening_barrier_ms, 3),
             "ms_per_step_reference_lists": round(ref_lists_ms, 4) if ref_lists_ms is not None else None,
