@@ -98,6 +98,15 @@ __device__ __forceinline__ float wave_sum9_rows(float v0, float v1, float v2, fl
 #ifndef GSR_BWD_XROW
 #define GSR_BWD_XROW 1
 #endif
+#ifndef GSR_BWD_EARLYMASK
+#define GSR_BWD_EARLYMASK 0  // 1: the log walk requests the next entry's masks right behind the first use of this entry's operands (pinned by scheduling
+                             // barriers) instead of with the LDS operands before the reduction -- meant to keep the scalar load out of the cross-row
+                             // exchange's lgkmcnt(0) wait; measured 0.2806 / 0.2819 against 0.2765 / 0.2779 ms: slower, off
+#endif
+#ifndef GSR_BWD_SMULADDR
+#define GSR_BWD_SMULADDR 1   // the entry's offset into the LDS sums by s_mul_i32 (0: the compiler's choice, a v_mad_u64_u32 with a register pair on either
+                             // side); measured 0.2742 / 0.2748 against 0.2765 / 0.2779 ms
+#endif
 template <bool XROW = false>
 __device__ __forceinline__ float wave_sum9_scatter(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
                                                    float v8, unsigned long long m0, unsigned long long m2)
@@ -596,6 +605,9 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
     const bool writer = gsr_sum9_writer(lane);
     const int my_slot = gsr_sum9_slot(lane);
     float* my_acc = s_acc + (NQ == 2 ? 0 : (wave >> 1) * BATCH * NV);
+    // this lane's slot of entry 0 as an INDEX into s_acc (32-bit arithmetic per reduction: through the pointer the compiler formed the
+    // address with a 64-bit v_mad_u64_u32 per reduction)
+    const uint32_t acc_slot0 = (uint32_t)((NQ == 2 ? 0 : (wave >> 1) * BATCH * NV) + my_slot);
     float* acc_lane = my_acc + gsr_sum9_mfma_slot0(lane);  // GSR_BWD_MFMA: where this lane's result registers 0, 1 (+ 8: register 2 of lane 0) go
     const bool w4 = (lane & 15) == 0, w1 = lane == 0;
     const int rounds = (int)((hi + BATCH - 1) / BATCH);
@@ -700,18 +712,27 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                 for (int q = 0; q < NQ; q++) mq[q] = ((bq[q] >> jj) & 1ull) ? mk.m[q] : 0ull;
                 const int jcur = j;
                 const bool more = U != 0ull;
-                // the NEXT entry's operands and masks, requested after this entry's quadrants and before its reduction: the registers
-                // are free by then and the round trips hide behind the reduction
+                // The NEXT entry's operands (LDS) are requested after this entry's quadrants and before its reduction: the registers are free
+                // by then and the round trip hides behind the reduction.  Its masks (a scalar load from L2 / HBM) are requested EARLIER, right
+                // behind the first use of this entry's operands (dy, cyy below): scalar loads return out of order, so while one is
+                // outstanding every wait for LDS data is a wait for it as well (lgkmcnt(0)) -- the wait for this entry's operands must lie
+                // in front of it, and the wait of the reduction's cross-row exchange as far behind it as possible (the visits and the
+                // in-row levels).  The scheduling barriers pin it there.
+                const int jjn = more ? (int)__builtin_ctzll(U) : jj;
+                U &= U - 1ull;
+                const int jn = 64 * w + jjn;
                 auto request_next = [&]() __attribute__((always_inline)) {
-                    const int jjn = more ? (int)__builtin_ctzll(U) : jj;
-                    U &= U - 1ull;
-                    const int jn = 64 * w + jjn;
                     na = s_a[jn]; nb = s_b[jn]; nc = s_c[jn];
-                    nm = load_masks(jn);
+                    if (!GSR_BWD_EARLYMASK) nm = load_masks(jn);
                     jj = jjn; j = jn;
                 };
                 const float dy = a.y - pyf;  // the wave's quadrants lie side by side: one dy per lane
                 const float cyy = (b.x * dy) * dy;  // shared by the wave's quadrants (same operation order as the forward's)
+                if (GSR_BWD_EARLYMASK) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    nm = load_masks(jn);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // one (entry, quadrant) visit with the forward's mask m_c != 0: what the quadrant leaves for the sums
                 auto visit = [&](auto Q, unsigned long long m_c, float& Wq, float& WXq, float& DXq, float& ATq) __attribute__((always_inline)) {
                     constexpr int q = decltype(Q)::value;
@@ -759,7 +780,13 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                     } else {
                         const float tot = wave_sum9_scatter<(GSR_BWD_XROW == 2 || (GSR_BWD_XROW == 1 && NQ == 2))>(sw, swx, swy, sxx, swx * dy, swy * dy, c0, c1,
                                                                                                                 c2, M0, M2);
-                        if (writer) atomicAdd(&my_acc[jcur * NV + my_slot], tot);  // LDS
+                        // (an LDS-typed pointer: 32-bit address arithmetic; through the generic pointer the compiler formed the address with a
+                        // 64-bit v_mad_u64_u32 per reduction)
+                        typedef __attribute__((address_space(3))) float lds_f32;
+                        uint32_t eoff = (uint32_t)jcur * NV;
+                        if (GSR_BWD_SMULADDR) asm("s_mul_i32 %0, %1, %2" : "=s"(eoff) : "s"((uint32_t)jcur), "n"(NV));  // (on the scalar side: the compiler picks a v_mad_u64_u32)
+                        if (writer)
+                            __hip_atomic_fetch_add((lds_f32*)s_acc + (acc_slot0 + eoff), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 };
                 // Each case is ONE straight-line block (two quadrants: their two chains -- sub, 6 mul/fma, exp, select, rcp, 10 mul/fma --
@@ -771,8 +798,9 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                         visit(std::integral_constant<int, 0>{}, mq[0], W0, WX0, DX0, AT0);
                         request_next();
                         reduce(W0, WX0, WX0 * DX0, AT0 * dL0[0], AT0 * dL1[0], AT0 * dL2[0]);
-                    } else
+                    } else {
                         request_next();
+                    }
                 } else {
                     const bool v0 = mq[0] != 0ull, v1 = mq[NQ - 1] != 0ull;
                     if (GSR_LOG_PROFILE == 2) {  // counting build: [1] entries walked, [2] both quadrants, [3] one, [4] none, [5] blended pixels
@@ -793,8 +821,9 @@ render_backward_log_kernel(int W, int H, int gx, int gy, const uint32_t* __restr
                         visit(std::integral_constant<int, NQ - 1>{}, mq[NQ - 1], W1, WX1, DX1, AT1);
                         request_next();
                         reduce(W1, WX1, WX1 * DX1, AT1 * dL0[NQ - 1], AT1 * dL1[NQ - 1], AT1 * dL2[NQ - 1]);
-                    } else
+                    } else {
                         request_next();
+                    }
                 }
                 return more;
             };

@@ -81,21 +81,36 @@ NS_SALU = 1.75
 VALU_BOUND = ("render_backward", "render_forward")  # the VALU-issue-bound kernels
 
 
-def price_list_cycles(v):
+def issue_shares():
+    """Static instruction shares of the blend kernels (profiles/blend_kernels_issue_shares.json, written by tools/r5_opcode_table.py): which
+    part of a kernel's fp32 fma instructions reads three registers and which part of its fp32 adds carries a DPP modifier -- the class
+    counters cannot tell, the issue costs differ by 1.7x."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "blend_kernels_issue_shares.json")))
+    except Exception:
+        return {}
+
+
+def price_list_cycles(v, shares=None):
     """Mean SIMD cycles per VALU instruction of a kernel from its PMC instruction-class counts (profiles/pmc_traffic.json) and the
-    measured price list of gfx950 (tools/valu_cost.hip): the counted plain classes (f32 add / mul / fma, int32) 2.4 cycles, transcendentals
-    (v_exp, v_rcp) 8.5, everything the class counters do not name -- compares, selects, lane reads, permlane swaps, converts, moves --
-    4.3.  DPP-modified adds are counted as plain adds and some of the unnamed instructions are plain moves, so this is an estimate of the
-    kernel's issue time, not a bound; None when the class counters are not on file.  (Round 5: int32 moved from the plain to the 4.3-cycle
-    class after tools/salu_probe.hip measured v_add_u32 / v_lshlrev_b32 at 1.77 ns.)"""
+    measured price list of gfx950 (tools/salu_probe.hip; ns per wave-instruction per SIMD x 2.4 GHz): fp32 add / mul and fma with two
+    register sources 2.4 cycles (0.95-1.0 ns); **fma reading three registers 4.0 (1.7 ns) and DPP adds 4.2 (1.76 ns)** -- the class counters
+    count them as plain fma / add, so their shares come from the static listing of the template instance that ran (`kernel_name` in the
+    PMC file, `shares`; without them everything counted as add / mul / fma is priced plain, as rounds 1-4 did); transcendentals (v_exp,
+    v_rcp) 8.5; everything the class counters do not name -- compares, selects, lane reads, int32, converts, moves from SGPRs -- 4.3 (some
+    of those are plain moves: an estimate of the kernel's issue time, not a bound).  None when the class counters are not on file."""
     need = ("sq_insts_valu", "sq_insts_valu_add_f32", "sq_insts_valu_mul_f32", "sq_insts_valu_fma_f32", "sq_insts_valu_int32",
             "sq_insts_valu_trans_f32")
     if not all(k in v for k in need):
         return None
-    plain = v["sq_insts_valu_add_f32"] + v["sq_insts_valu_mul_f32"] + v["sq_insts_valu_fma_f32"]  # (round 5: int32 is NOT plain: 1.77 ns)
+    name = v.get("kernel_name")
+    f3 = (shares or {}).get("three_register_share_of_fp32_fma", {}).get(name, 0.0)
+    dpp = (shares or {}).get("dpp_share_of_fp32_add", {}).get(name, 0.0)
+    add, mul, fma = v["sq_insts_valu_add_f32"], v["sq_insts_valu_mul_f32"], v["sq_insts_valu_fma_f32"]
     trans = v["sq_insts_valu_trans_f32"]
-    other = max(v["sq_insts_valu"] - plain - trans, 0.0)
-    return (2.4 * plain + 8.5 * trans + 4.3 * other) / v["sq_insts_valu"]
+    other = max(v["sq_insts_valu"] - add - mul - fma - trans, 0.0)
+    cycles = 2.4 * (add * (1.0 - dpp) + mul + fma * (1.0 - f3)) + 4.2 * add * dpp + 4.0 * fma * f3 + 8.5 * trans + 4.3 * other
+    return cycles / v["sq_insts_valu"]
 FP32_VALU_PEAK_TFLOPS = 157.3
 
 
@@ -815,7 +830,7 @@ def main():
                 # two is VALU-issue bound.
                 k["valu_insts"] = int(v["sq_insts_valu"])
                 k["simd_cycles_per_valu_inst"] = round(1024 * 2.4e9 * k["avg_ms"] * 1e-3 / v["sq_insts_valu"], 2)
-                pl = price_list_cycles(v)
+                pl = price_list_cycles(v, issue_shares())
                 if pl is not None:
                     k["price_list_cycles_per_valu_inst"] = round(pl, 2)
             if "hbm_bytes" in v:

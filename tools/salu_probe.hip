@@ -16,6 +16,7 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
 {
     float a = threadIdx.x * 1e-3f, b = 1.0001f, c = 0.5f, d = 0.25f;
     float2 p0 = {a, 1.f}, p1 = {1.0001f, 0.999f}, p2 = {0.5f, 0.25f}, p3 = {0.125f, 0.3f};
+    unsigned long long q0 = threadIdx.x, q1 = threadIdx.x * 7ull;
     uint32_t va = threadIdx.x, vb = threadIdx.x * 3u;
     unsigned long long s0 = 0x1234567ull + blockIdx.x, s1 = 0xFFFF0000FFFFull, s2 = 0xF0F0F0F0ull, s3 = 0xFF00FF00FFull;
     uint32_t t0 = blockIdx.x + 1, t1 = 77, t2 = 5, t3 = 9;
@@ -49,9 +50,18 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
         else if (KIND == 26) asm volatile(R16("v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_shl:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         else if (KIND == 27) asm volatile(R16("v_add_f32 %0, %0, %1\n v_mul_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_mul_f32 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         else if (KIND == 28) asm volatile(R16("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 30) asm volatile(R16("v_mad_u64_u32 %0, vcc, %2, 36, %0\n v_mad_u64_u32 %1, vcc, %3, 36, %1\n v_mad_u64_u32 %0, vcc, %2, 36, %0\n v_mad_u64_u32 %1, vcc, %3, 36, %1\n") : "+v"(q0), "+v"(q1) : "s"(t0), "s"(t1) : "vcc");
+        else if (KIND == 31) asm volatile(R16("v_mul_legacy_f32 %0, %0, %1\n v_mul_legacy_f32 %1, %1, %2\n v_mul_legacy_f32 %2, %2, %3\n v_mul_legacy_f32 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 32) asm volatile(R16("v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_fmac_f32 %3, %0, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 33) asm volatile(R16("v_fmaak_f32 %0, %0, %1, 0x3d635a47\n v_fmaak_f32 %1, %1, %2, 0x3d635a47\n v_fmaak_f32 %2, %2, %3, 0x3d635a47\n v_fmaak_f32 %3, %3, %0, 0x3d635a47\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 34) asm volatile(R16("v_mul_f32_e64 %0, %0, -%1\n v_mul_f32_e64 %1, %1, -%2\n v_mul_f32_e64 %2, %2, -%3\n v_mul_f32_e64 %3, %3, -%0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 35) asm volatile(R16("v_mul_f32 %0, 0x3fb8aa3b, %1\n v_mul_f32 %1, 0x3fb8aa3b, %2\n v_mul_f32 %2, 0x3fb8aa3b, %3\n v_mul_f32 %3, 0x3fb8aa3b, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 36) asm volatile(R16("v_fma_f32 %0, %1, %2, %3\n v_fma_f32 %1, %2, %3, %0\n v_fma_f32 %2, %3, %0, %1\n v_fma_f32 %3, %0, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 37) asm volatile(R16("v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %1, %1, %1, %2\n v_fma_f32 %2, %2, %2, %3\n v_fma_f32 %3, %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         else if (KIND == 29) asm volatile(R16("v_pk_mov_b32 %0, %1, %2\n v_pk_mov_b32 %1, %2, %3\n v_pk_mov_b32 %2, %3, %0\n v_pk_mov_b32 %3, %0, %1\n") : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
     }
     if (p0.x + p1.y + p2.x + p3.y == 777.5f) out[1] = p0.x;
+    if (q0 + q1 == 0x123456789abcull) out[2] = 1.f;
     if (a + b + c + d == 12345.678f || (s0 ^ s1 ^ s2 ^ s3) == 0x123456789ull || t0 + t1 + t2 + t3 == 0x7777777u || va + vb == 0x3333333u) out[0] = a;
 }
 
@@ -111,5 +121,15 @@ int main()
     run<27>("v_add_f32 / v_mul_f32", 64, sink);
     run<28>("v_mov_b32 vgpr", 64, sink);
     run<29>("v_pk_mov_b32", 64, sink);
+    run<30>("v_mad_u64_u32 (sgpr x const + vgpr pair)", 64, sink);
+    run<31>("v_mul_legacy_f32", 64, sink);
+    run<19>("v_fma_f32 (again, warm clocks)", 64, sink);
+    run<32>("v_fmac_f32 (VOP2)", 64, sink);
+    run<33>("v_fmaak_f32 (VOP2 + 32-bit literal)", 64, sink);
+    run<34>("v_mul_f32_e64 (VOP3, neg modifier)", 64, sink);
+    run<35>("v_mul_f32 with a 32-bit literal", 64, sink);
+    run<36>("v_fma_f32 three distinct sources", 64, sink);
+    run<37>("v_fma_f32 two distinct sources", 64, sink);
+    run<27>("v_add_f32 / v_mul_f32 (again)", 64, sink);
     return 0;
 }
