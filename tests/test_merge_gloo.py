@@ -285,3 +285,28 @@ def test_bench_partitions_fill_the_single_gpu_scene_volume():
             assert torch.all(hi[:2] - lo[:2] < 8.0 + 1e-4) and torch.all(hi[:2] - lo[:2] > 7.9)
             assert abs(float(0.5 * (lo[0] + hi[0])) - centre[0]) < 0.05 and abs(float(0.5 * (lo[1] + hi[1])) - centre[1]) < 0.05
             assert box == syn.partition_origin_box(r, world, cell=bench.PARTITION_CELL)
+
+
+def test_bench_price_list_prices_three_register_fmas_and_dpp_adds():
+    """bench.price_list_cycles: the class counters call a DPP add an add and a three-register fma an fma; their shares come from the static
+    listing of the template instance that ran (profiles/blend_kernels_issue_shares.json), and the committed PMC profile names that instance."""
+    import json
+
+    import bench
+
+    v = {"sq_insts_valu": 100.0, "sq_insts_valu_add_f32": 30.0, "sq_insts_valu_mul_f32": 30.0, "sq_insts_valu_fma_f32": 20.0,
+         "sq_insts_valu_int32": 0.0, "sq_insts_valu_trans_f32": 4.0, "kernel_name": "k<2>"}
+    plain = bench.price_list_cycles(v)  # no shares: everything counted as add / mul / fma is plain
+    assert abs(plain - (2.4 * 80 + 8.5 * 4 + 4.3 * 16) / 100) < 1e-9
+    shares = {"three_register_share_of_fp32_fma": {"k<2>": 0.5}, "dpp_share_of_fp32_add": {"k<2>": 1.0}}
+    priced = bench.price_list_cycles(v, shares)
+    assert abs(priced - (2.4 * (30 + 10) + 4.2 * 30 + 4.0 * 10 + 8.5 * 4 + 4.3 * 16) / 100) < 1e-9
+    assert bench.price_list_cycles({"sq_insts_valu": 1.0}) is None
+    # the committed files fit together: the profile names the instance, the shares file knows it
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pmc = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    sh = bench.issue_shares()
+    for stage in ("render_backward", "render_forward"):
+        name = pmc[stage]["kernel_name"]
+        assert name in sh["three_register_share_of_fp32_fma"] and name in sh["dpp_share_of_fp32_add"]
+        assert bench.price_list_cycles(pmc[stage], sh) >= bench.price_list_cycles(pmc[stage])
